@@ -1,0 +1,166 @@
+/*
+ * s2k.h -- C ABI of the MI355X-native k-min-mer extraction engine.
+ *
+ * This is the drop-in boundary for ONE path of rchikhi/rust-seq2kminmers: "reads in -> ordered
+ * stream of k-min-mers out".  In the reference that path is
+ *     KminmersIterator::new(seq, l, k, density, mode)      src/lib.rs:89-131
+ *     impl Iterator for KminmersIterator { Item = KminmerHash }   src/lib.rs:179-270
+ *     struct KminmerHash { hash, start, end, offset, rev }  src/kminmer.rs:128-135
+ * called once per read from a thread pool (src/main.rs:65-79).  A GPU needs >= 10^4 reads per
+ * launch, so the ABI is batch-oriented: n_reads reads stored back to back, one call, SoA results;
+ * the per-read Iterator shape is rebuilt on top of it by include/s2k.hpp (C++) and by the Rust shim
+ * shown in INTEGRATION.md.  The crate's own precedent for an opaque-handle C ABI is
+ * src/nthash_c.rs:14-29 (create / roll / get / destroy).
+ *
+ * Conventions: plain C types only; the caller owns inputs; the library owns s2k_result buffers until
+ * s2k_result_free(); nothing panics or throws across the ABI -- parameter violations that make the
+ * reference panic (src/lib.rs:99 unwrap of KSizeTooBig, src/nthash_hpc.rs:133 assert!(k<256),
+ * src/lib.rs:246 underflow at k==0) come back as status codes.  One s2k_ctx per (thread, device);
+ * contexts are independent.  All results are bit-exact to the reference's scalar path
+ * (HashMode::Regular / HashMode::Hpc); the Simd / HpcSimd *result semantics* (strict '<', f32 bound,
+ * start-of-run end, kept last l-mer, low-nibble seed map -- SURVEY.md 8a traps i-vi) are selectable.
+ */
+#ifndef S2K_H
+#define S2K_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2K_ABI_VERSION 1
+
+typedef struct s2k_ctx s2k_ctx; /* opaque; cf. nthashc_create/destroy, src/nthash_c.rs:14-29 */
+
+typedef enum s2k_status {
+    S2K_OK = 0,
+    S2K_ERR_INVALID_ARG = 1,   /* NULL pointer, non-monotone read_off, unknown mode */
+    S2K_ERR_L_RANGE = 2,       /* l == 0 or l >= 256 (src/nthash_hpc.rs:123-125,133); Simd modes: l > 31 (src/nthash_avx512_32.rs:33) */
+    S2K_ERR_K_RANGE = 3,       /* k == 0 (src/lib.rs:246 would underflow) or k > 4096 */
+    S2K_ERR_READ_TOO_LONG = 4, /* a read longer than 2^32-2 bases (positions are u32, cf. src/nthash_hpc_simd.rs:26) */
+    S2K_ERR_DEVICE = 5,        /* HIP runtime error; s2k_last_error() has the text */
+    S2K_ERR_NOMEM = 6,
+    S2K_ERR_CAPACITY = 7,      /* caller-provided device output too small; counts say what is needed */
+    S2K_ERR_NO_DEVICE = 8,     /* no gfx950 device visible: there is NO CPU fallback */
+    S2K_ERR_NON_ASCII = 9      /* a base >= 0x80 met by the tiled kernels in a mode that cannot take it; see s2k_extract */
+} s2k_status;
+
+/* HashMode, src/lib.rs:21-27 */
+typedef enum s2k_mode {
+    S2K_MODE_REGULAR = 0, /* src/lib.rs:215-230 */
+    S2K_MODE_HPC = 1,     /* NtHashHPCIterator, src/nthash_hpc.rs:115-283 */
+    S2K_MODE_SIMD = 2,    /* result semantics of NtHashSIMDIterator, src/nthash_avx512_32.rs:32-164 */
+    S2K_MODE_HPCSIMD = 3  /* result semantics of NtHashHPCSIMDIterator, src/nthash_hpc_simd.rs:35-68 */
+} s2k_mode;
+
+enum {
+    S2K_FLAG_WANT_MINIMIZERS = 1u << 0, /* also return the (j, jend, hash32) triples (NtHashHPCIterator::Item, src/nthash_hpc.rs:193) */
+    S2K_FLAG_FORCE_SERIAL = 1u << 1     /* use the read-serial kernels (exact for every input; slow) instead of the tiled ones */
+};
+
+typedef struct s2k_params {
+    uint32_t l;       /* minimizer length            (src/lib.rs:89 `l`) */
+    uint32_t k;       /* k-min-mer order             (src/lib.rs:89 `k`) */
+    double density;   /* FH = f64                    (src/lib.rs:34,89) */
+    int32_t mode;     /* s2k_mode */
+    uint32_t flags;
+} s2k_params;
+
+typedef struct s2k_counts {
+    uint64_t n_reads;
+    uint64_t n_bases;
+    uint64_t n_minimizers;
+    uint64_t n_kminmers;
+    uint64_t xor_hash;   /* XOR of all k-min-mer hashes (cheap whole-run checksum) */
+    uint32_t hash_bound; /* the u32 bound of src/lib.rs:91 that was used */
+    uint32_t path;       /* 0 = tiled kernels, 1 = read-serial kernels */
+} s2k_counts;
+
+/* Host-side result, SoA.  Item i of read r (km_off[r] <= i < km_off[r+1]) is
+ * KminmerHash{ hash[i], start[i], end[i], offset = i - km_off[r], rev[i] }  (src/kminmer.rs:128-135). */
+typedef struct s2k_result {
+    uint64_t n_reads;
+    uint64_t n_kminmers;
+    uint64_t *km_off; /* n_reads + 1 */
+    uint64_t *hash;   /* KH = u64, src/lib.rs:37 */
+    uint32_t *start;
+    uint32_t *end;
+    uint8_t *rev;
+    /* only with S2K_FLAG_WANT_MINIMIZERS, else NULL / 0 */
+    uint64_t n_minimizers;
+    uint64_t *mn_off; /* n_reads + 1 */
+    uint32_t *mn_j;
+    uint32_t *mn_jend;
+    uint32_t *mn_hash; /* H = u32, src/lib.rs:31 */
+    s2k_counts counts;
+    void *_owner;
+} s2k_result;
+
+/* Device-resident output buffers provided by the caller (device pointers, capacities in items). */
+typedef struct s2k_device_out {
+    uint64_t km_capacity;
+    uint64_t *km_off; /* n_reads + 1, required */
+    uint64_t *hash;   /* may be NULL to skip */
+    uint32_t *start;
+    uint32_t *end;
+    uint8_t *rev;
+    uint64_t mn_capacity; /* 0 => minimizer triples not wanted */
+    uint64_t *mn_off;
+    uint32_t *mn_j;
+    uint32_t *mn_jend;
+    uint32_t *mn_hash;
+} s2k_device_out;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int s2k_abi_version(void);
+int s2k_device_count(void);
+/* Creates a context on HIP device `device`.  Fails with S2K_ERR_NO_DEVICE when no GPU is visible. */
+s2k_ctx *s2k_create(int device, s2k_status *status);
+void s2k_destroy(s2k_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
+s2k_status s2k_set_stream(s2k_ctx *ctx, void *hip_stream);
+const char *s2k_strerror(s2k_status st);
+const char *s2k_last_error(const s2k_ctx *ctx);
+
+/* (density * u32::MAX as f64) as u32 -- src/lib.rs:91 */
+uint32_t s2k_hash_bound(double density);
+
+/* ---- the hot path ---------------------------------------------------------------------------- */
+/* Replaces: for each read r { KminmersIterator::new(&bases[read_off[r]..read_off[r+1]], l, k, density,
+ * mode)?.collect() } -- src/lib.rs:89,179 driven by src/main.rs:65-79.  Host buffers in, host SoA out
+ * (library-owned; release with s2k_result_free).  Reads with len <= l yield nothing (src/lib.rs:97). */
+s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
+                       const s2k_params *params, s2k_result *out);
+void s2k_result_free(s2k_result *res);
+
+/* Same computation with inputs and outputs resident in HBM.  Enqueued on the context's stream; if
+ * `counts` is non-NULL the call waits for completion and fills it (and returns S2K_ERR_CAPACITY if
+ * an output capacity was too small -- counts then hold the required sizes).  With counts == NULL the
+ * call returns after enqueueing; s2k_sync() later waits and reports the same status/counts. */
+s2k_status s2k_extract_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_read_off,
+                              uint64_t n_reads, uint64_t n_bases, const s2k_params *params,
+                              const s2k_device_out *out, s2k_counts *counts);
+s2k_status s2k_sync(s2k_ctx *ctx, s2k_counts *counts);
+
+/* ---- standalone homopolymer compression (src/hpc.rs:28-41 hpc, :44-147 encode_rle_simd) ---------- */
+/* Per read: compressed string + run-start positions (read-relative).  d_hpc_off: n_reads+1 prefix of
+ * run counts; d_hpc / d_pos (either may be NULL) receive up to `capacity` entries. */
+s2k_status s2k_hpc_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+                          uint64_t n_bases, uint64_t *d_hpc_off, uint8_t *d_hpc, uint32_t *d_pos,
+                          uint64_t capacity, uint64_t *n_runs);
+
+/* ---- helpers for device-resident benchmarking ------------------------------------------------- */
+/* Fills d_bases[0..n) with the deterministic synthetic ACGT stream (splitmix64 keyed by seed and
+ * absolute base index; same function as oracle/s2k_oracle.c:s2k_oracle_synth_bases). */
+s2k_status s2k_synth_bases_device(s2k_ctx *ctx, uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_bases);
+/* Duration in ms of the kernels of the last s2k_extract_device call, measured with HIP events on the
+ * context's stream: which: 0 = whole pipeline, 1 = the minimizer kernel (dominant), 2 = k-min-mer kernel. */
+s2k_status s2k_last_kernel_ms(s2k_ctx *ctx, int which, float *ms);
+s2k_status s2k_enable_timing(s2k_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2K_H */

@@ -1,0 +1,326 @@
+"""rust-seq2kminmers_amd -- host-side mirror of the reference's seq -> k-min-mer interface over the
+MI355X C ABI (include/s2k.h, built from csrc/ into csrc/libs2k.so).
+
+Reference interface mirrored here (names, argument meaning, error behaviour):
+    KminmersIterator::new(seq, l, k, density, mode)   src/lib.rs:89-131
+    impl Iterator { type Item = KminmerHash }         src/lib.rs:179-270
+    KminmerHash{hash,start,end,offset,rev}, ==/ord by hash only   src/kminmer.rs:128-135,181-204
+    HashMode{Regular,Hpc,Simd,HpcSimd}                src/lib.rs:21-27
+    hpc(), encode_rle_simd()                          src/hpc.rs:28-41, 44-147
+
+There is no CPU fallback: importing works anywhere (so the CPU test tier can check the ABI), but
+creating an Engine without a GPU raises.  The directory name carries a hyphen (as the task names it),
+so load it with `import_package()` from s2k_loader.py or importlib.
+"""
+import ctypes as C
+import enum
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libs2k.so")
+
+ABI_SYMBOLS = [
+    "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_strerror",
+    "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
+    "s2k_hpc_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing",
+]
+
+
+class HashMode(enum.IntEnum):  # src/lib.rs:21-27
+    Regular = 0
+    Hpc = 1
+    Simd = 2
+    HpcSimd = 3
+
+
+FLAG_WANT_MINIMIZERS = 1
+FLAG_FORCE_SERIAL = 2
+
+
+class S2kError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("s2k status %d: %s" % (status, msg))
+        self.status = status
+
+
+class Params(C.Structure):
+    _fields_ = [("l", C.c_uint32), ("k", C.c_uint32), ("density", C.c_double), ("mode", C.c_int32), ("flags", C.c_uint32)]
+
+
+class Counts(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_minimizers", C.c_uint64), ("n_kminmers", C.c_uint64),
+                ("xor_hash", C.c_uint64), ("hash_bound", C.c_uint32), ("path", C.c_uint32)]
+
+    def as_dict(self):
+        return {f: int(getattr(self, f)) for f, _ in self._fields_}
+
+
+_u8p, _u32p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+
+
+class Result(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_kminmers", C.c_uint64), ("km_off", _u64p), ("hash", _u64p), ("start", _u32p),
+                ("end", _u32p), ("rev", _u8p), ("n_minimizers", C.c_uint64), ("mn_off", _u64p), ("mn_j", _u32p),
+                ("mn_jend", _u32p), ("mn_hash", _u32p), ("counts", Counts), ("_owner", C.c_void_p)]
+
+
+class DeviceOut(C.Structure):
+    _fields_ = [("km_capacity", C.c_uint64), ("km_off", C.c_void_p), ("hash", C.c_void_p), ("start", C.c_void_p),
+                ("end", C.c_void_p), ("rev", C.c_void_p), ("mn_capacity", C.c_uint64), ("mn_off", C.c_void_p),
+                ("mn_j", C.c_void_p), ("mn_jend", C.c_void_p), ("mn_hash", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the C-ABI library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError("%s is missing: build it with `make -C %s` (or __graft_entry__.build())" % (p, os.path.dirname(p)))
+    L = C.CDLL(p)
+    L.s2k_abi_version.restype = C.c_int
+    L.s2k_device_count.restype = C.c_int
+    L.s2k_create.restype = C.c_void_p
+    L.s2k_create.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    L.s2k_destroy.argtypes = [C.c_void_p]
+    L.s2k_destroy.restype = None
+    L.s2k_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.s2k_strerror.restype = C.c_char_p
+    L.s2k_strerror.argtypes = [C.c_int]
+    L.s2k_last_error.restype = C.c_char_p
+    L.s2k_last_error.argtypes = [C.c_void_p]
+    L.s2k_hash_bound.restype = C.c_uint32
+    L.s2k_hash_bound.argtypes = [C.c_double]
+    L.s2k_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Params), C.POINTER(Result)]
+    L.s2k_result_free.argtypes = [C.POINTER(Result)]
+    L.s2k_result_free.restype = None
+    L.s2k_extract_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(Params),
+                                     C.POINTER(DeviceOut), C.POINTER(Counts)]
+    L.s2k_sync.argtypes = [C.c_void_p, C.POINTER(Counts)]
+    L.s2k_hpc_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.s2k_synth_bases_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.s2k_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.s2k_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    if path is None:
+        _lib = L
+    return L
+
+
+def hash_bound(density):
+    """(density * u32::MAX as f64) as u32 -- src/lib.rs:91"""
+    return int(load_library().s2k_hash_bound(float(density)))
+
+
+def _as_u8(seq):
+    if isinstance(seq, str):
+        seq = seq.encode("latin-1")
+    if isinstance(seq, (bytes, bytearray, memoryview)):
+        return np.frombuffer(bytes(seq), dtype=np.uint8)
+    return np.ascontiguousarray(seq, dtype=np.uint8)
+
+
+def pack_reads(reads):
+    """list of byte strings -> (bases u8[total], read_off u64[n+1])"""
+    arrs = [_as_u8(r) for r in reads]
+    off = np.zeros(len(arrs) + 1, dtype=np.uint64)
+    if arrs:
+        off[1:] = np.cumsum([len(a) for a in arrs], dtype=np.uint64)
+    bases = np.concatenate(arrs) if arrs and int(off[-1]) else np.zeros(0, dtype=np.uint8)
+    return np.ascontiguousarray(bases, dtype=np.uint8), off
+
+
+class Engine:
+    """One s2k_ctx (one per thread and device, like one KminmersIterator per thread in src/main.rs:65-79)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        st = C.c_int(0)
+        self.ctx = self.lib.s2k_create(int(device), C.byref(st))
+        if not self.ctx:
+            raise S2kError(st.value, self.lib.s2k_strerror(st.value).decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.s2k_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            raise S2kError(st, self.lib.s2k_strerror(st).decode() + " -- " + self.lib.s2k_last_error(self.ctx).decode())
+
+    def set_stream(self, hip_stream_handle):
+        self._check(self.lib.s2k_set_stream(self.ctx, C.c_void_p(int(hip_stream_handle))))
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.s2k_enable_timing(self.ctx, 1 if on else 0))
+
+    def last_kernel_ms(self, which):
+        ms = C.c_float(0)
+        self._check(self.lib.s2k_last_kernel_ms(self.ctx, which, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- host-buffer API (s2k_extract) ---------------------------------------------------------------
+    def extract(self, bases, read_off, l, k, density, mode=HashMode.Hpc, want_minimizers=False, force_serial=False):
+        """Batch counterpart of `for r in reads: KminmersIterator::new(r,l,k,d,mode).collect()`.
+        Returns a dict of numpy arrays (copies)."""
+        bases = _as_u8(bases)
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        n_reads = len(read_off) - 1
+        flags = (FLAG_WANT_MINIMIZERS if want_minimizers else 0) | (FLAG_FORCE_SERIAL if force_serial else 0)
+        p = Params(int(l), int(k), float(density), int(mode), flags)
+        res = Result()
+        self._check(self.lib.s2k_extract(self.ctx, bases.ctypes.data_as(C.c_void_p), read_off.ctypes.data_as(C.c_void_p),
+                                         n_reads, C.byref(p), C.byref(res)))
+        try:
+            nk, nm = int(res.n_kminmers), int(res.n_minimizers)
+
+            def take(ptr, n, dt):
+                if n == 0:
+                    return np.zeros(0, dtype=dt)
+                return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+
+            out = {
+                "n": nk, "km_off": take(res.km_off, n_reads + 1, np.uint64), "hash": take(res.hash, nk, np.uint64),
+                "start": take(res.start, nk, np.uint32), "end": take(res.end, nk, np.uint32), "rev": take(res.rev, nk, np.uint8),
+                "counts": res.counts.as_dict(),
+            }
+            if want_minimizers:
+                out.update({"n_minimizers": nm, "mn_off": take(res.mn_off, n_reads + 1, np.uint64),
+                            "mn_j": take(res.mn_j, nm, np.uint32), "mn_jend": take(res.mn_jend, nm, np.uint32),
+                            "mn_hash": take(res.mn_hash, nm, np.uint32)})
+            return out
+        finally:
+            self.lib.s2k_result_free(C.byref(res))
+
+    def extract_reads(self, reads, l, k, density, mode=HashMode.Hpc, **kw):
+        bases, off = pack_reads(reads)
+        return self.extract(bases, off, l, k, density, mode, **kw)
+
+    # ---- device-resident API (s2k_extract_device); pointers are integers (e.g. torch .data_ptr()) ------
+    def extract_device(self, d_bases, d_read_off, n_reads, n_bases, l, k, density, mode, out, sync=True, flags=0):
+        p = Params(int(l), int(k), float(density), int(mode), int(flags))
+        cnt = Counts()
+        st = self.lib.s2k_extract_device(self.ctx, C.c_void_p(d_bases), C.c_void_p(d_read_off), n_reads, n_bases, C.byref(p),
+                                         C.byref(out), C.byref(cnt) if sync else None)
+        self._check(st)
+        return cnt.as_dict() if sync else None
+
+    def sync(self):
+        cnt = Counts()
+        self._check(self.lib.s2k_sync(self.ctx, C.byref(cnt)))
+        return cnt.as_dict()
+
+    def synth_bases_device(self, seed, first_base, n, d_ptr):
+        self._check(self.lib.s2k_synth_bases_device(self.ctx, seed, first_base, n, C.c_void_p(d_ptr)))
+
+    def hpc_device(self, d_bases, d_read_off, n_reads, n_bases, d_hpc_off, d_hpc, d_pos, capacity):
+        n = C.c_uint64(0)
+        st = self.lib.s2k_hpc_device(self.ctx, C.c_void_p(d_bases), C.c_void_p(d_read_off), n_reads, n_bases,
+                                     C.c_void_p(d_hpc_off), C.c_void_p(d_hpc or 0), C.c_void_p(d_pos or 0), capacity, C.byref(n))
+        self._check(st)
+        return int(n.value)
+
+
+_default_engine = None
+
+
+def default_engine():
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine(0)
+    return _default_engine
+
+
+class KminmerHash:
+    """src/kminmer.rs:128-135; equality and ordering by `hash` only (src/kminmer.rs:181-204)."""
+    __slots__ = ("hash", "start", "end", "offset", "rev")
+
+    def __init__(self, hash, start, end, offset, rev):
+        self.hash, self.start, self.end, self.offset, self.rev = hash, start, end, offset, rev
+
+    @classmethod
+    def new_from_hash(cls, hash, start, end, offset, rev):  # src/kminmer.rs:169-177
+        return cls(hash, start, end, offset, rev)
+
+    def get_hash(self):  # src/kminmer.rs:162-164
+        return self.hash
+
+    def __eq__(self, o):
+        return self.hash == o.hash
+
+    def __lt__(self, o):
+        return self.hash < o.hash
+
+    def __hash__(self):
+        return hash(self.hash)
+
+    def __repr__(self):  # Debug formatting of the Rust struct
+        return "KminmerHash { hash: %d, start: %d, end: %d, offset: %d, rev: %s }" % (
+            self.hash, self.start, self.end, self.offset, "true" if self.rev else "false")
+
+
+class KminmersIterator:
+    """Per-read facade with the reference's constructor signature (src/lib.rs:89) and Iterator shape
+    (src/lib.rs:179-181).  One GPU call per read is the wrong granularity for throughput -- use
+    Engine.extract for batches; this class exists so reference-style call sites and tests read the same.
+    Parameter violations that panic in the reference raise S2kError here."""
+
+    def __init__(self, seq, l, k, density, mode=HashMode.Hpc, engine=None):
+        eng = engine or default_engine()
+        r = eng.extract_reads([seq], l, k, density, mode)
+        self._r = r
+        self._i = 0
+
+    @classmethod
+    def new(cls, seq, l, k, density, mode, engine=None):
+        return cls(seq, l, k, density, mode, engine)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        i = self._i
+        if i >= self._r["n"]:
+            raise StopIteration
+        self._i += 1
+        r = self._r
+        return KminmerHash(int(r["hash"][i]), int(r["start"][i]), int(r["end"][i]), i, bool(r["rev"][i]))
+
+
+def hpc(seq, engine=None):
+    """Homopolymer-compressed string of one read (any equal bytes collapse): src/hpc.rs:28-41.
+    (The reference's hpc("") returns "#"; an empty read yields an empty string here.)"""
+    s, _ = encode_rle_simd(seq, engine)
+    return s
+
+
+def encode_rle_simd(seq, engine=None):
+    """(compressed string, run-start positions) -- src/hpc.rs:44-147 -- computed on the GPU."""
+    import torch
+
+    eng = engine or default_engine()
+    a = _as_u8(seq)
+    n = len(a)
+    dev = torch.device("cuda", eng.device)
+    d_b = torch.from_numpy(a.copy()).to(dev) if n else torch.zeros(1, dtype=torch.uint8, device=dev)
+    d_off = torch.tensor([0, n], dtype=torch.int64, device=dev)
+    d_ho = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_h = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+    d_p = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    r = eng.hpc_device(d_b.data_ptr(), d_off.data_ptr(), 1, n, d_ho.data_ptr(), d_h.data_ptr(), d_p.data_ptr(), max(n, 1))
+    return d_h[:r].cpu().numpy().tobytes(), d_p[:r].cpu().numpy().astype(np.uint32)

@@ -1,0 +1,603 @@
+// s2k_api.hip -- the C ABI of include/s2k.h: context, workspace arena, and the two kernel pipelines
+// (tiled = fast path, serial = exact fallback).  There is NO CPU path in this library: without a GPU
+// s2k_create() fails with S2K_ERR_NO_DEVICE.
+#include "../../include/s2k.h"
+#include "s2k_dev.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace s2k;
+
+static_assert(offsetof(Counts, path) == offsetof(s2k_counts, path), "Counts must start with s2k_counts");
+
+namespace {
+
+struct HostOwner { // backing store of an s2k_result
+    std::vector<uint64_t> km_off, hash, mn_off;
+    std::vector<uint32_t> start, end, mn_j, mn_jend, mn_hash;
+    std::vector<uint8_t> rev;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            bytes = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = need + need / 8 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return e;
+        bytes = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct Arena {
+    char *base;
+    size_t off, cap;
+    template <class T> T *take(size_t n) {
+        size_t o = (off + 255) & ~(size_t)255;
+        off = o + n * sizeof(T);
+        return base ? reinterpret_cast<T *>(base + o) : nullptr;
+    }
+};
+
+struct Call { // everything needed to (re-)enqueue one extraction
+    const uint8_t *d_bases = nullptr;
+    const uint64_t *d_read_off = nullptr;
+    uint64_t n_reads = 0, n_bases = 0;
+    s2k_params params{};
+    s2k_device_out out{};
+    Sem sem{};
+    uint32_t bound = 0;
+    bool serial = false;
+    uint64_t pool_cap = 0;
+    bool valid = false;
+};
+
+} // namespace
+
+struct s2k_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf ws, in_bases, in_off, outbuf;
+    Counts *d_counts = nullptr;
+    Counts *h_counts = nullptr; // pinned
+    uint64_t *d_xor = nullptr;
+    hipEvent_t ev[6]{};
+    bool timing = false, timed = false;
+    Call call;
+    bool pending = false;
+    s2k_status pending_status = S2K_OK;
+    std::string err;
+};
+
+namespace {
+
+s2k_status fail(s2k_ctx *c, s2k_status st, const char *what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return st;
+}
+
+#define S2K_TRY(expr, what)                                               \
+    do {                                                                  \
+        hipError_t _e = (expr);                                           \
+        if (_e != hipSuccess) return fail(ctx, S2K_ERR_DEVICE, what, _e); \
+    } while (0)
+
+// src/lib.rs:91 -- ((density as FH) * (H::MAX as FH)) as H ; float->int `as` saturates, NaN -> 0
+uint32_t hash_bound(double density) {
+    double v = density * 4294967295.0;
+    if (!(v == v) || v <= 0.0) return 0;
+    if (v >= 4294967295.0) return 4294967295u;
+    return (uint32_t)v;
+}
+// src/nthash_avx512_32.rs:46-48 -- density re-derived from the bound, then through f32
+uint32_t hash_bound_simd(uint32_t b) {
+    double density = (double)b / 4294967295.0;
+    float f = (float)density * 4294967296.0f;
+    if (!(f == f) || f <= 0.0f) return 0;
+    if (f >= 4294967296.0f) return 4294967295u;
+    return (uint32_t)f;
+}
+
+s2k_status resolve_sem(s2k_ctx *ctx, const s2k_params *p, Sem *s, uint32_t *bound_out) {
+    if (!p) return fail(ctx, S2K_ERR_INVALID_ARG, "params is NULL");
+    if (p->l == 0 || p->l >= 256) return fail(ctx, S2K_ERR_L_RANGE, "l must be in [1,255] (src/nthash_hpc.rs:123-133)");
+    if (p->k == 0 || p->k > 4096) return fail(ctx, S2K_ERR_K_RANGE, "k must be in [1,4096]");
+    uint32_t b = hash_bound(p->density);
+    *bound_out = b;
+    memset(s, 0, sizeof *s);
+    s->l = p->l;
+    s->k = p->k;
+    switch (p->mode) {
+    case S2K_MODE_REGULAR: // src/lib.rs:215-230
+        s->bound_le = b; s->enabled = 1; s->hpc = 0; s->simd_seeds = 0; s->keep_last = 1; s->end_kind = 0; s->tail_quirk = 0;
+        break;
+    case S2K_MODE_HPC: // src/nthash_hpc.rs:115-283
+        s->bound_le = b; s->enabled = 1; s->hpc = 1; s->simd_seeds = 0; s->keep_last = 0; s->end_kind = 1; s->tail_quirk = 0;
+        break;
+    case S2K_MODE_SIMD:    // src/nthash_avx512_32.rs:32-164
+    case S2K_MODE_HPCSIMD: // src/nthash_hpc_simd.rs:35-68
+    {
+        if (p->l > 31) return fail(ctx, S2K_ERR_L_RANGE, "Simd modes need l <= 31 (src/nthash_avx512_32.rs:33)");
+        uint32_t b2 = hash_bound_simd(b);
+        s->enabled = b2 != 0; // strict '<' (nthash_avx512_32.rs:55,130)
+        s->bound_le = b2 ? b2 - 1 : 0;
+        s->hpc = p->mode == S2K_MODE_HPCSIMD;
+        s->simd_seeds = 1;
+        s->keep_last = 1;
+        s->end_kind = s->hpc ? 2 : 0;
+        s->tail_quirk = 1;
+        break;
+    }
+    default: return fail(ctx, S2K_ERR_INVALID_ARG, "unknown mode");
+    }
+    return S2K_OK;
+}
+
+// expected number of minimizers, padded: canonical min of two strands passes with prob ~ 1-(1-d)^2
+uint64_t pool_estimate(uint64_t n_bases, uint64_t n_units, double density, bool hpc) {
+    double d = density < 0 ? 0 : (density > 1 ? 1 : density);
+    double p = 1.0 - (1.0 - d) * (1.0 - d);
+    double est = (double)n_bases * p * (hpc ? 0.85 : 1.0) * 1.15 + 64.0 * sqrt((double)n_bases * p + 1.0);
+    uint64_t cap = (uint64_t)est + 4 * n_units + (uint64_t)TILE_BASES + 4096;
+    if (cap > n_bases + 4096) cap = n_bases + 4096;
+    return cap;
+}
+
+bool tiled_supported(const Sem &s) {
+    // the tiled kernel implements the two scalar HashModes (the parity target); the Simd result
+    // semantics run on the serial kernels
+    return !s.simd_seeds && s.l <= 64;
+}
+
+s2k_status enqueue(s2k_ctx *ctx) {
+    Call &c = ctx->call;
+    const uint64_t n_reads = c.n_reads, n_bases = c.n_bases;
+    const uint64_t n_tiles = c.serial ? n_reads : (n_bases + TILE_BASES - 1) / TILE_BASES;
+    const s2k_device_out &o = c.out;
+    hipStream_t st = ctx->stream;
+
+    // ---- carve the workspace (first pass sizes, second pass pointers) --------------------------
+    Arena a{nullptr, 0, 0};
+    uint32_t *mn_cnt = nullptr, *tile_read0 = nullptr, *tile_cnt = nullptr;
+    uint64_t *mn_off = nullptr, *tile_rec_off = nullptr, *tile_goff = nullptr, *scan_tmp = nullptr, *pool_cursor = nullptr;
+    Records rec{};
+    for (int pass = 0; pass < 2; pass++) {
+        a.off = 0;
+        mn_cnt = a.take<uint32_t>(n_reads + 1);
+        mn_off = o.mn_off ? o.mn_off : a.take<uint64_t>(n_reads + 1);
+        if (o.mn_off) (void)0;
+        scan_tmp = a.take<uint64_t>(scan_tmp_bytes(n_reads > n_tiles ? n_reads : n_tiles) / sizeof(uint64_t) + 1);
+        pool_cursor = a.take<uint64_t>(4);
+        if (!c.serial) {
+            tile_read0 = a.take<uint32_t>(n_tiles + 1);
+            tile_cnt = a.take<uint32_t>(n_tiles + 1);
+            tile_rec_off = a.take<uint64_t>(n_tiles + 1);
+            tile_goff = a.take<uint64_t>(n_tiles + 1);
+        }
+        rec.j = a.take<uint32_t>(c.pool_cap);
+        rec.jend = a.take<uint32_t>(c.pool_cap);
+        rec.hash = a.take<uint32_t>(c.pool_cap);
+        rec.rid = a.take<uint32_t>(c.pool_cap);
+        rec.capacity = c.pool_cap;
+        if (pass == 0) {
+            S2K_TRY(ctx->ws.ensure(a.off + 256), "workspace allocation");
+            a.base = (char *)ctx->ws.p;
+        }
+    }
+    if (c.serial) {
+        tile_cnt = mn_cnt;
+        tile_goff = mn_off;
+        tile_rec_off = mn_off;
+    }
+
+    const bool tm = ctx->timing;
+    ctx->timed = tm;
+    if (tm) S2K_TRY(hipEventRecord(ctx->ev[0], st), "event");
+    S2K_TRY(hipMemsetAsync(ctx->d_counts, 0, sizeof(Counts), st), "memset counts");
+    S2K_TRY(hipMemsetAsync(ctx->d_xor, 0, XOR_SHARDS * sizeof(uint64_t), st), "memset xor");
+    S2K_TRY(hipMemsetAsync(pool_cursor, 0, 4 * sizeof(uint64_t), st), "memset cursor");
+
+    if (c.serial) {
+        if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
+        S2K_TRY(launch_serial_count(c.d_bases, c.d_read_off, n_reads, c.sem, mn_cnt, st), "serial count kernel");
+        S2K_TRY(launch_scan_u32(mn_cnt, n_reads, mn_off, scan_tmp, 0, st), "scan");
+        S2K_TRY(launch_serial_write(c.d_bases, c.d_read_off, n_reads, c.sem, mn_off, rec, ctx->d_counts, st), "serial write kernel");
+        if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
+    } else {
+        S2K_TRY(hipMemsetAsync(mn_cnt, 0, (n_reads + 1) * sizeof(uint32_t), st), "memset mn_cnt");
+        S2K_TRY(launch_tile_index(c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, st), "tile index kernel");
+        if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
+        S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, c.sem, rec, pool_cursor,
+                                       tile_rec_off, tile_cnt, mn_cnt, ctx->d_counts, st),
+                "tiled minimizer kernel");
+        if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
+        S2K_TRY(launch_scan_u32(tile_cnt, n_tiles, tile_goff, scan_tmp, 0, st), "scan");
+        S2K_TRY(launch_scan_u32(mn_cnt, n_reads, mn_off, scan_tmp, 0, st), "scan");
+    }
+    S2K_TRY(launch_scan_u32(mn_cnt, n_reads, o.km_off, scan_tmp, c.sem.k, st), "scan");
+    if (tm) S2K_TRY(hipEventRecord(ctx->ev[3], st), "event");
+    S2K_TRY(launch_kminmers(n_tiles, tile_rec_off, tile_cnt, tile_goff, rec, mn_off, o.km_off, c.sem.k, o.km_capacity, o.hash,
+                            o.start, o.end, o.rev, o.mn_capacity, o.mn_capacity ? o.mn_j : nullptr, o.mn_jend, o.mn_hash,
+                            ctx->d_xor, ctx->d_counts, st),
+            "k-min-mer kernel");
+    if (tm) S2K_TRY(hipEventRecord(ctx->ev[4], st), "event");
+    S2K_TRY(launch_finalize(ctx->d_counts, ctx->d_xor, mn_off + n_reads, o.km_off + n_reads, o.km_capacity, o.mn_capacity, st),
+            "finalize kernel");
+    S2K_TRY(hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(Counts), hipMemcpyDeviceToHost, st), "counts copy");
+    if (tm) S2K_TRY(hipEventRecord(ctx->ev[5], st), "event");
+    ctx->pending = true;
+    return S2K_OK;
+}
+
+s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
+    if (!ctx->pending) {
+        if (counts && ctx->call.valid) memcpy(counts, ctx->h_counts, sizeof(s2k_counts));
+        return ctx->pending_status;
+    }
+    for (int attempt = 0; attempt < 4; attempt++) {
+        S2K_TRY(hipStreamSynchronize(ctx->stream), "stream synchronize");
+        ctx->pending = false;
+        Counts *h = ctx->h_counts;
+        Call &c = ctx->call;
+        if (!c.serial && h->non_ascii) { // tiled kernels met a byte >= 0x80 in Hpc mode: exact fallback
+            c.serial = true;
+            c.pool_cap = pool_estimate(c.n_bases, c.n_reads, c.params.density, c.sem.hpc);
+            s2k_status st = enqueue(ctx);
+            if (st != S2K_OK) return st;
+            continue;
+        }
+        if (h->pool_overflow) { // minimizer record pool was too small: re-run with the exact size
+            c.pool_cap = h->pool_needed + h->pool_needed / 64 + (uint64_t)TILE_BASES + 4096;
+            s2k_status st = enqueue(ctx);
+            if (st != S2K_OK) return st;
+            continue;
+        }
+        h->n_reads = c.n_reads;
+        h->n_bases = c.n_bases;
+        h->hash_bound = c.bound;
+        h->path = c.serial ? 1u : 0u;
+        if (counts) memcpy(counts, h, sizeof(s2k_counts));
+        ctx->pending_status = (h->km_overflow || h->mn_overflow) ? S2K_ERR_CAPACITY : S2K_OK;
+        if (ctx->pending_status != S2K_OK) ctx->err = "device output capacity too small; see counts";
+        return ctx->pending_status;
+    }
+    return fail(ctx, S2K_ERR_DEVICE, "workspace retry did not converge");
+}
+
+} // namespace
+
+// =================================================================================================
+extern "C" {
+
+int s2k_abi_version(void) { return S2K_ABI_VERSION; }
+
+int s2k_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *s2k_strerror(s2k_status st) {
+    switch (st) {
+    case S2K_OK: return "ok";
+    case S2K_ERR_INVALID_ARG: return "invalid argument";
+    case S2K_ERR_L_RANGE: return "minimizer length l out of range";
+    case S2K_ERR_K_RANGE: return "k-min-mer order k out of range";
+    case S2K_ERR_READ_TOO_LONG: return "a read is longer than 2^32-2 bases";
+    case S2K_ERR_DEVICE: return "HIP runtime error";
+    case S2K_ERR_NOMEM: return "out of memory";
+    case S2K_ERR_CAPACITY: return "device output capacity too small";
+    case S2K_ERR_NO_DEVICE: return "no GPU visible (this library has no CPU path)";
+    case S2K_ERR_NON_ASCII: return "input holds bytes >= 0x80";
+    }
+    return "unknown status";
+}
+
+const char *s2k_last_error(const s2k_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+uint32_t s2k_hash_bound(double density) { return hash_bound(density); }
+
+s2k_ctx *s2k_create(int device, s2k_status *status) {
+    s2k_status dummy;
+    if (!status) status = &dummy;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        *status = S2K_ERR_NO_DEVICE;
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        *status = S2K_ERR_INVALID_ARG;
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        *status = S2K_ERR_DEVICE;
+        return nullptr;
+    }
+    s2k_ctx *ctx = new (std::nothrow) s2k_ctx();
+    if (!ctx) {
+        *status = S2K_ERR_NOMEM;
+        return nullptr;
+    }
+    ctx->device = device;
+    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    ctx->own_stream = ok;
+    ok = ok && hipMalloc((void **)&ctx->d_counts, sizeof(Counts)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_xor, XOR_SHARDS * sizeof(uint64_t)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_counts, sizeof(Counts), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; ok && i < 6; i++) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
+    if (!ok) {
+        *status = S2K_ERR_DEVICE;
+        s2k_destroy(ctx);
+        return nullptr;
+    }
+    memset(ctx->h_counts, 0, sizeof(Counts));
+    *status = S2K_OK;
+    return ctx;
+}
+
+void s2k_destroy(s2k_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->ws.release();
+    ctx->in_bases.release();
+    ctx->in_off.release();
+    ctx->outbuf.release();
+    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    if (ctx->d_xor) (void)hipFree(ctx->d_xor);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    for (int i = 0; i < 6; i++)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+s2k_status s2k_set_stream(s2k_ctx *ctx, void *hip_stream) {
+    if (!ctx) return S2K_ERR_INVALID_ARG;
+    if (ctx->pending) {
+        s2k_status st = finish(ctx, nullptr);
+        (void)st;
+    }
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return S2K_OK;
+}
+
+s2k_status s2k_enable_timing(s2k_ctx *ctx, int on) {
+    if (!ctx) return S2K_ERR_INVALID_ARG;
+    ctx->timing = on != 0;
+    return S2K_OK;
+}
+
+s2k_status s2k_last_kernel_ms(s2k_ctx *ctx, int which, float *ms) {
+    if (!ctx || !ms || which < 0 || which > 2) return S2K_ERR_INVALID_ARG;
+    if (!ctx->timed) return fail(ctx, S2K_ERR_INVALID_ARG, "timing was not enabled for the last call");
+    if (ctx->pending) {
+        s2k_status st = finish(ctx, nullptr);
+        if (st != S2K_OK && st != S2K_ERR_CAPACITY) return st;
+    }
+    int a = which == 0 ? 0 : which == 1 ? 1 : 3, b = which == 0 ? 5 : which == 1 ? 2 : 4;
+    S2K_TRY(hipEventElapsedTime(ms, ctx->ev[a], ctx->ev[b]), "event elapsed");
+    return S2K_OK;
+}
+
+s2k_status s2k_extract_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+                              uint64_t n_bases, const s2k_params *params, const s2k_device_out *out,
+                              s2k_counts *counts) {
+    if (!ctx) return S2K_ERR_INVALID_ARG;
+    if (ctx->pending) {
+        s2k_status st = finish(ctx, nullptr);
+        if (st != S2K_OK && st != S2K_ERR_CAPACITY) return st;
+    }
+    if (!out || !out->km_off || !d_read_off || (!d_bases && n_bases)) return fail(ctx, S2K_ERR_INVALID_ARG, "NULL device pointer");
+    if (n_reads >= 0xFFFFFFFFull) return fail(ctx, S2K_ERR_INVALID_ARG, "too many reads in one call");
+    if (out->mn_capacity && !(out->mn_j && out->mn_jend && out->mn_hash)) return fail(ctx, S2K_ERR_INVALID_ARG, "mn_capacity set but minimizer arrays missing");
+    S2K_TRY(hipSetDevice(ctx->device), "set device");
+    Call &c = ctx->call;
+    c = Call();
+    s2k_status st = resolve_sem(ctx, params, &c.sem, &c.bound);
+    if (st != S2K_OK) return st;
+    c.d_bases = d_bases;
+    c.d_read_off = d_read_off;
+    c.n_reads = n_reads;
+    c.n_bases = n_bases;
+    c.params = *params;
+    c.out = *out;
+    // the tiled kernel stages tiles with 16 B vector loads: it needs a 16 B aligned base pointer
+    c.serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(c.sem) || (((uintptr_t)d_bases) & 15u) != 0;
+    c.pool_cap = pool_estimate(n_bases, c.serial ? n_reads : (n_bases + TILE_BASES - 1) / TILE_BASES, params->density, c.sem.hpc);
+    c.valid = true;
+    ctx->pending_status = S2K_OK;
+    st = enqueue(ctx);
+    if (st != S2K_OK) return st;
+    if (counts) return finish(ctx, counts);
+    return S2K_OK;
+}
+
+s2k_status s2k_sync(s2k_ctx *ctx, s2k_counts *counts) {
+    if (!ctx) return S2K_ERR_INVALID_ARG;
+    return finish(ctx, counts);
+}
+
+s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
+                       const s2k_params *params, s2k_result *res) {
+    if (!ctx || !res) return S2K_ERR_INVALID_ARG;
+    memset(res, 0, sizeof *res);
+    if (!read_off) return fail(ctx, S2K_ERR_INVALID_ARG, "read_off is NULL");
+    Sem sem;
+    uint32_t bound;
+    s2k_status st = resolve_sem(ctx, params, &sem, &bound);
+    if (st != S2K_OK) return st;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        if (read_off[r + 1] < read_off[r]) return fail(ctx, S2K_ERR_INVALID_ARG, "read_off is not monotone");
+        if (read_off[r + 1] - read_off[r] > 0xFFFFFFFEull) return fail(ctx, S2K_ERR_READ_TOO_LONG, "read too long");
+    }
+    const uint64_t first = read_off[0], n_bases = read_off[n_reads] - first;
+    if (n_bases && !bases) return fail(ctx, S2K_ERR_INVALID_ARG, "bases is NULL");
+    S2K_TRY(hipSetDevice(ctx->device), "set device");
+    if (ctx->pending) (void)finish(ctx, nullptr);
+
+    // inputs -> HBM (+ 64 B of slack so vector loads of the last tile stay inside the allocation)
+    S2K_TRY(ctx->in_bases.ensure(n_bases + 256), "input allocation");
+    S2K_TRY(ctx->in_off.ensure((n_reads + 1) * sizeof(uint64_t)), "input allocation");
+    std::vector<uint64_t> off(n_reads + 1);
+    for (uint64_t r = 0; r <= n_reads; r++) off[r] = read_off[r] - first;
+    if (n_bases) S2K_TRY(hipMemcpyAsync(ctx->in_bases.p, bases + first, n_bases, hipMemcpyHostToDevice, ctx->stream), "H2D bases");
+    S2K_TRY(hipMemcpyAsync(ctx->in_off.p, off.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream), "H2D offsets");
+    S2K_TRY(hipStreamSynchronize(ctx->stream), "H2D sync");
+
+    const bool want_mn = params->flags & S2K_FLAG_WANT_MINIMIZERS;
+    const bool serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(sem);
+    uint64_t cap = pool_estimate(n_bases, serial ? n_reads : (n_bases + TILE_BASES - 1) / TILE_BASES, params->density, sem.hpc);
+    s2k_counts cnt;
+    s2k_device_out o;
+    for (int attempt = 0;; attempt++) {
+        // km <= minimizers <= cap, so one capacity serves every output array
+        Arena a{nullptr, 0, 0};
+        for (int pass = 0; pass < 2; pass++) {
+            a.off = 0;
+            memset(&o, 0, sizeof o);
+            o.km_capacity = cap;
+            o.km_off = a.take<uint64_t>(n_reads + 1);
+            o.hash = a.take<uint64_t>(cap);
+            o.start = a.take<uint32_t>(cap);
+            o.end = a.take<uint32_t>(cap);
+            o.rev = a.take<uint8_t>(cap);
+            if (want_mn) {
+                o.mn_capacity = cap;
+                o.mn_off = a.take<uint64_t>(n_reads + 1);
+                o.mn_j = a.take<uint32_t>(cap);
+                o.mn_jend = a.take<uint32_t>(cap);
+                o.mn_hash = a.take<uint32_t>(cap);
+            }
+            if (pass == 0) {
+                S2K_TRY(ctx->outbuf.ensure(a.off + 256), "output allocation");
+                a.base = (char *)ctx->outbuf.p;
+            }
+        }
+        st = s2k_extract_device(ctx, (const uint8_t *)ctx->in_bases.p, (const uint64_t *)ctx->in_off.p, n_reads, n_bases,
+                                params, &o, &cnt);
+        if (st == S2K_ERR_CAPACITY && attempt < 3) {
+            cap = (cnt.n_minimizers > cnt.n_kminmers ? cnt.n_minimizers : cnt.n_kminmers) + 4096;
+            continue;
+        }
+        if (st != S2K_OK) return st;
+        break;
+    }
+
+    HostOwner *ow = new (std::nothrow) HostOwner();
+    if (!ow) return fail(ctx, S2K_ERR_NOMEM, "host result allocation");
+    const uint64_t nk = cnt.n_kminmers, nm = cnt.n_minimizers;
+    ow->km_off.resize(n_reads + 1);
+    ow->hash.resize(nk);
+    ow->start.resize(nk);
+    ow->end.resize(nk);
+    ow->rev.resize(nk);
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemcpyAsync(ow->km_off.data(), o.km_off, (n_reads + 1) * 8, hipMemcpyDeviceToHost, s);
+    if (nk && e == hipSuccess) e = hipMemcpyAsync(ow->hash.data(), o.hash, nk * 8, hipMemcpyDeviceToHost, s);
+    if (nk && e == hipSuccess) e = hipMemcpyAsync(ow->start.data(), o.start, nk * 4, hipMemcpyDeviceToHost, s);
+    if (nk && e == hipSuccess) e = hipMemcpyAsync(ow->end.data(), o.end, nk * 4, hipMemcpyDeviceToHost, s);
+    if (nk && e == hipSuccess) e = hipMemcpyAsync(ow->rev.data(), o.rev, nk, hipMemcpyDeviceToHost, s);
+    if (want_mn && e == hipSuccess) {
+        ow->mn_off.resize(n_reads + 1);
+        ow->mn_j.resize(nm);
+        ow->mn_jend.resize(nm);
+        ow->mn_hash.resize(nm);
+        e = hipMemcpyAsync(ow->mn_off.data(), o.mn_off, (n_reads + 1) * 8, hipMemcpyDeviceToHost, s);
+        if (nm && e == hipSuccess) e = hipMemcpyAsync(ow->mn_j.data(), o.mn_j, nm * 4, hipMemcpyDeviceToHost, s);
+        if (nm && e == hipSuccess) e = hipMemcpyAsync(ow->mn_jend.data(), o.mn_jend, nm * 4, hipMemcpyDeviceToHost, s);
+        if (nm && e == hipSuccess) e = hipMemcpyAsync(ow->mn_hash.data(), o.mn_hash, nm * 4, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        delete ow;
+        return fail(ctx, S2K_ERR_DEVICE, "D2H results", e);
+    }
+    res->n_reads = n_reads;
+    res->n_kminmers = nk;
+    res->km_off = ow->km_off.data();
+    res->hash = ow->hash.data();
+    res->start = ow->start.data();
+    res->end = ow->end.data();
+    res->rev = ow->rev.data();
+    if (want_mn) {
+        res->n_minimizers = nm;
+        res->mn_off = ow->mn_off.data();
+        res->mn_j = ow->mn_j.data();
+        res->mn_jend = ow->mn_jend.data();
+        res->mn_hash = ow->mn_hash.data();
+    }
+    res->counts = cnt;
+    res->_owner = ow;
+    return S2K_OK;
+}
+
+void s2k_result_free(s2k_result *res) {
+    if (!res || !res->_owner) return;
+    delete reinterpret_cast<HostOwner *>(res->_owner);
+    memset(res, 0, sizeof *res);
+}
+
+s2k_status s2k_synth_bases_device(s2k_ctx *ctx, uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_bases) {
+    if (!ctx || (!d_bases && n)) return S2K_ERR_INVALID_ARG;
+    S2K_TRY(hipSetDevice(ctx->device), "set device");
+    S2K_TRY(launch_synth(seed, first_base, n, d_bases, ctx->stream), "synth kernel");
+    return S2K_OK;
+}
+
+s2k_status s2k_hpc_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+                          uint64_t n_bases, uint64_t *d_hpc_off, uint8_t *d_hpc, uint32_t *d_pos, uint64_t capacity,
+                          uint64_t *n_runs) {
+    if (!ctx || !d_read_off || !d_hpc_off || (!d_bases && n_bases)) return S2K_ERR_INVALID_ARG;
+    S2K_TRY(hipSetDevice(ctx->device), "set device");
+    if (ctx->pending) (void)finish(ctx, nullptr);
+    Arena a{nullptr, 0, 0};
+    uint32_t *cnt = nullptr;
+    uint64_t *tmp = nullptr;
+    for (int pass = 0; pass < 2; pass++) {
+        a.off = 0;
+        cnt = a.take<uint32_t>(n_reads + 1);
+        tmp = a.take<uint64_t>(scan_tmp_bytes(n_reads) / sizeof(uint64_t) + 1);
+        if (pass == 0) {
+            S2K_TRY(ctx->ws.ensure(a.off + 256), "workspace allocation");
+            a.base = (char *)ctx->ws.p;
+        }
+    }
+    S2K_TRY(launch_hpc_count(d_bases, d_read_off, n_reads, cnt, ctx->stream), "hpc count kernel");
+    S2K_TRY(launch_scan_u32(cnt, n_reads, d_hpc_off, tmp, 0, ctx->stream), "scan");
+    if (d_hpc || d_pos) S2K_TRY(launch_hpc_write(d_bases, d_read_off, n_reads, d_hpc_off, d_hpc, d_pos, capacity, ctx->stream), "hpc write kernel");
+    uint64_t total = 0;
+    S2K_TRY(hipMemcpyAsync(&total, d_hpc_off + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H");
+    S2K_TRY(hipStreamSynchronize(ctx->stream), "sync");
+    if (n_runs) *n_runs = total;
+    return total > capacity && (d_hpc || d_pos) ? S2K_ERR_CAPACITY : S2K_OK;
+}
+
+} // extern "C"

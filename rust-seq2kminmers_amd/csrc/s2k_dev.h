@@ -1,0 +1,121 @@
+// s2k_dev.h -- shared device/host definitions for the gfx950 kernels.
+// Semantics follow the reference's scalar path; citations are to /root/reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace s2k {
+
+// low 32 bits of the ntHash1 seeds (`as H`, H = u32): src/nthash_hpc.rs:30-49, src/lib.rs:31
+constexpr uint32_t SEED_A = 0x95c60474u, SEED_C = 0x62a02b4cu, SEED_G = 0x82572324u, SEED_T = 0x4be24456u;
+
+// scalar-path tables: N -> 0, every other byte -> 1 (src/nthash_hpc.rs:31,36,42,47)
+__host__ __device__ inline uint32_t seed_h_scalar(uint32_t c) {
+    return c == 'A' ? SEED_A : c == 'C' ? SEED_C : c == 'G' ? SEED_G : c == 'T' ? SEED_T : c == 'N' ? 0u : 1u;
+}
+__host__ __device__ inline uint32_t seed_rc_scalar(uint32_t c) {
+    return c == 'A' ? SEED_T : c == 'C' ? SEED_G : c == 'G' ? SEED_C : c == 'T' ? SEED_A : c == 'N' ? 0u : 1u;
+}
+// AVX-512-path mapping: low nibble 1->A 3->C 7->G 4->T, everything else -> 0
+// (src/nthash_avx512_32.rs:178-193 pshufb table, :225-262 permutexvar seeds)
+__host__ __device__ inline uint32_t seed_h_simd(uint32_t c) {
+    uint32_t n = c & 15u;
+    return n == 1 ? SEED_A : n == 3 ? SEED_C : n == 7 ? SEED_G : n == 4 ? SEED_T : 0u;
+}
+__host__ __device__ inline uint32_t seed_rc_simd(uint32_t c) {
+    uint32_t n = c & 15u;
+    return n == 1 ? SEED_T : n == 3 ? SEED_G : n == 7 ? SEED_C : n == 4 ? SEED_A : 0u;
+}
+
+__host__ __device__ inline uint32_t rotl32(uint32_t x, uint32_t r) { r &= 31u; return (x << r) | (x >> ((32u - r) & 31u)); }
+__host__ __device__ inline uint32_t rotr32(uint32_t x, uint32_t r) { r &= 31u; return (x >> r) | (x << ((32u - r) & 31u)); }
+__host__ __device__ inline uint64_t rotl64(uint64_t x, uint32_t r) { r &= 63u; return (x << r) | (x >> ((64u - r) & 63u)); }
+
+// MixHash for u32: xorshift 13/7/17 on the zero-extended value -- src/lib.rs:157-169
+__host__ __device__ inline uint64_t mix32(uint32_t h) {
+    uint64_t x = h;
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    return x;
+}
+
+// What a HashMode means, resolved on the host (s2k_api.hip:resolve_sem).
+struct Sem {
+    uint32_t l;
+    uint32_t k;
+    uint32_t bound_le;   // keep iff hash <= bound_le (strict '<' modes use bound-1) ...
+    uint32_t enabled;    // ... and only if enabled (strict '<' with bound 0 keeps nothing)
+    uint32_t hpc;        // minimizers in homopolymer-compressed space
+    uint32_t simd_seeds; // low-nibble seed mapping (Simd/HpcSimd)
+    uint32_t keep_last;  // Hpc scalar drops the last HPC l-mer (src/nthash_hpc.rs:265-267); others keep theirs
+    uint32_t end_kind;   // 0: j+l-1 (lib.rs:202,226)  1: st[p+l]-1 (nthash_hpc.rs:281)  2: st[p+l-1] (nthash_hpc_simd.rs:64)
+    uint32_t tail_quirk; // drop the final 16-block when #l-mers % 16 == 0 (src/nthash_avx512_32.rs:134-138)
+};
+
+struct Counts { // mirrored by s2k_counts (include/s2k.h)
+    uint64_t n_reads, n_bases, n_minimizers, n_kminmers, xor_hash;
+    uint32_t hash_bound, path;
+    // internal
+    uint64_t pool_needed;
+    uint32_t pool_overflow, non_ascii, km_overflow, mn_overflow;
+};
+
+constexpr int XOR_SHARDS = 4096;
+
+// tile geometry of the tiled minimizer kernel (s2k_tile.hip)
+constexpr int TILE_T = 144;              // bases per lane
+constexpr int TILE_BASES = 64 * TILE_T;  // 9216 bases per wave-tile
+
+// Orders LDS traffic between the lanes of ONE wave (no workgroup barrier: waves of a block run
+// independent tiles with different trip counts).  A wave's DS operations execute in program order, so
+// a wavefront-scope fence -- which only constrains the compiler and the wave's own waitcnts -- is enough.
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct Records { // SoA pool of minimizer records written by the minimizer kernels
+    uint32_t *j, *jend, *hash, *rid;
+    uint64_t capacity;
+};
+
+#define S2K_HIP_CHECK(expr)                                                      \
+    do {                                                                         \
+        hipError_t _e = (expr);                                                  \
+        if (_e != hipSuccess) return _e;                                         \
+    } while (0)
+
+// ---- host launchers implemented in the kernel translation units --------------------------------
+hipError_t launch_scan_u32(const uint32_t *in, uint64_t n, uint64_t *out /*n+1*/, uint64_t *block_tmp,
+                           uint32_t sub_k /*0: identity, else max(0,x-sub_k+1)*/, hipStream_t st);
+size_t scan_tmp_bytes(uint64_t n);
+
+hipError_t launch_synth(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d, hipStream_t st);
+
+hipError_t launch_serial_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, Sem sem,
+                               uint32_t *mn_cnt, hipStream_t st);
+hipError_t launch_serial_write(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, Sem sem,
+                               const uint64_t *mn_off, Records rec, Counts *counts, hipStream_t st);
+
+hipError_t launch_kminmers(uint64_t n_tiles, const uint64_t *tile_rec_off, const uint32_t *tile_cnt,
+                           const uint64_t *tile_goff, Records rec, const uint64_t *mn_off, const uint64_t *km_off,
+                           uint32_t k, uint64_t km_capacity, uint64_t *o_hash, uint32_t *o_start, uint32_t *o_end,
+                           uint8_t *o_rev, uint64_t mn_capacity, uint32_t *o_mn_j, uint32_t *o_mn_jend,
+                           uint32_t *o_mn_hash, uint64_t *xor_shards, const Counts *counts, hipStream_t st);
+hipError_t launch_finalize(Counts *counts, const uint64_t *xor_shards, const uint64_t *mn_total, const uint64_t *km_total,
+                           uint64_t km_capacity, uint64_t mn_capacity, hipStream_t st);
+
+hipError_t launch_tile_index(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles,
+                             uint32_t *tile_read0, hipStream_t st);
+hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
+                                  uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec,
+                                  uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
+                                  Counts *counts, hipStream_t st);
+
+hipError_t launch_hpc_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint32_t *run_cnt, hipStream_t st);
+hipError_t launch_hpc_write(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, const uint64_t *hpc_off,
+                            uint8_t *o_hpc, uint32_t *o_pos, uint64_t capacity, hipStream_t st);
+
+} // namespace s2k

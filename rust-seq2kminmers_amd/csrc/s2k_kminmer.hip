@@ -1,0 +1,151 @@
+// s2k_kminmer.hip -- k-min-mer emission (the tail of KminmersIterator::next, src/lib.rs:231-266).
+//
+// The reference keeps a rolling pair (kminmer_fhash, kminmer_rhash) per read (lib.rs:238-249).  The
+// k-min-mer hash is a pure function of k consecutive mixed minimizer hashes (closed form:
+// lib.rs:275-288), so here every window is computed independently:
+//     F  = XOR_i rotl64(mix(m[c+i]), k-1-i)     Rv = XOR_i rotl64(mix(m[c+i]), i)
+//     item = KminmerHash{ min(F,Rv), start = j[c], end = jend[c+k-1], offset = c, rev = Rv < F }   (lib.rs:250-258)
+//
+// Input: minimizer records grouped in "tiles" (a stream tile of the tiled kernel, or a whole read for
+// the serial kernels).  Tiles are in stream order and records inside a tile are in position order, so
+// the concatenation of tiles is the global minimizer sequence sorted by (read, position); tile_goff is
+// its exclusive prefix.  One wave per tile; 64 records per round; the round's mixed hashes plus the
+// k-1 records that follow (possibly in later tiles) are staged in LDS.
+#include "s2k_dev.h"
+
+namespace s2k {
+namespace {
+
+constexpr int KM_WAVES = 4;       // waves per block
+constexpr int KM_LDS_K = 65;      // windows up to this k are served from LDS
+constexpr int KM_WIN = 64 + KM_LDS_K - 1;
+
+struct Cursor {
+    uint64_t tile;
+    uint64_t idx;
+};
+
+// advance (tile, idx) so that idx < tile_cnt[tile]; returns false past the last tile
+__device__ inline bool normalize(Cursor &c, const uint32_t *__restrict__ tile_cnt, uint64_t n_tiles) {
+    while (c.tile < n_tiles) {
+        uint32_t n = tile_cnt[c.tile];
+        if (c.idx < n) return true;
+        c.idx -= n;
+        c.tile++;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64 * KM_WAVES) void kminmer_kernel(
+    uint64_t n_tiles, const uint64_t *__restrict__ tile_rec_off, const uint32_t *__restrict__ tile_cnt,
+    const uint64_t *__restrict__ tile_goff, Records rec, const uint64_t *__restrict__ mn_off,
+    const uint64_t *__restrict__ km_off, uint32_t k, uint64_t km_capacity, uint64_t *__restrict__ o_hash,
+    uint32_t *__restrict__ o_start, uint32_t *__restrict__ o_end, uint8_t *__restrict__ o_rev, uint64_t mn_capacity,
+    uint32_t *__restrict__ o_mn_j, uint32_t *__restrict__ o_mn_jend, uint32_t *__restrict__ o_mn_hash,
+    uint64_t *__restrict__ xor_shards, const Counts *__restrict__ counts) {
+    __shared__ uint64_t s_x[KM_WAVES][KM_WIN];
+    __shared__ uint32_t s_je[KM_WAVES][KM_WIN];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t t = (uint64_t)blockIdx.x * KM_WAVES + w;
+    if (t >= n_tiles) return; // whole wave exits together; no block-level barrier below
+    if (counts->pool_overflow) return; // record pool was too small: offsets are not valid, the host re-runs
+    const uint32_t cnt = tile_cnt[t];
+    if (cnt == 0) return;
+    const uint64_t roff = tile_rec_off[t];
+    const uint64_t g0 = tile_goff[t];
+    const bool lds_path = k <= (uint32_t)KM_LDS_K;
+    uint64_t xacc = 0;
+
+    for (uint32_t base = 0; base < cnt; base += 64) {
+        const uint32_t i = base + lane;
+        const bool have = i < cnt;
+        uint32_t j = 0, je = 0, hv = 0, rid = 0;
+        if (have) {
+            j = rec.j[roff + i];
+            je = rec.jend[roff + i];
+            hv = rec.hash[roff + i];
+            rid = rec.rid[roff + i];
+        }
+        const uint64_t g = g0 + i;
+        if (lds_path) {
+            wave_sync(); // LDS rows are wave-private: order this round's writes after the previous round's reads
+            s_x[w][lane] = mix32(hv);
+            s_je[w][lane] = je;
+            // entries 64 .. 64+k-2 : records that follow this round's 64
+            for (uint32_t e = 64 + lane; e < 64 + k - 1; e += 64) {
+                Cursor c{t, (uint64_t)base + e};
+                uint64_t x = 0;
+                uint32_t jj = 0;
+                if (normalize(c, tile_cnt, n_tiles)) {
+                    uint64_t a = tile_rec_off[c.tile] + c.idx;
+                    x = mix32(rec.hash[a]);
+                    jj = rec.jend[a];
+                }
+                s_x[w][e] = x;
+                s_je[w][e] = jj;
+            }
+            wave_sync();
+        }
+        if (have) {
+            const uint64_t m0 = mn_off[rid];
+            const uint64_t c = g - m0;          // rank of this minimizer inside its read
+            const uint64_t M = mn_off[rid + 1] - m0;
+            if (o_mn_j && g < mn_capacity) {
+                o_mn_j[g] = j;
+                o_mn_jend[g] = je;
+                o_mn_hash[g] = hv;
+            }
+            if (c + k <= M) { // window c..c+k-1 lies inside the read: item `c` exists (lib.rs:235)
+                uint64_t F = 0, Rv = 0;
+                uint32_t end;
+                if (lds_path) {
+                    for (uint32_t m = 0; m < k; m++) {
+                        uint64_t x = s_x[w][lane + m];
+                        F ^= rotl64(x, k - 1 - m);
+                        Rv ^= rotl64(x, m);
+                    }
+                    end = s_je[w][lane + k - 1];
+                } else {
+                    Cursor cur{t, i};
+                    end = je;
+                    for (uint32_t m = 0; m < k; m++) {
+                        normalize(cur, tile_cnt, n_tiles);
+                        uint64_t a = tile_rec_off[cur.tile] + cur.idx;
+                        uint64_t x = mix32(rec.hash[a]);
+                        F ^= rotl64(x, k - 1 - m);
+                        Rv ^= rotl64(x, m);
+                        if (m == k - 1) end = rec.jend[a];
+                        cur.idx++;
+                    }
+                }
+                const uint64_t o = km_off[rid] + c;
+                const uint64_t hmin = F < Rv ? F : Rv;
+                xacc ^= hmin;
+                if (o < km_capacity) {
+                    if (o_hash) o_hash[o] = hmin;
+                    if (o_start) o_start[o] = j;
+                    if (o_end) o_end[o] = end;
+                    if (o_rev) o_rev[o] = (uint8_t)(Rv < F);
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) xacc ^= __shfl_down(xacc, o);
+    if (lane == 0 && xacc) atomicXor((unsigned long long *)&xor_shards[t & (XOR_SHARDS - 1)], (unsigned long long)xacc);
+}
+
+} // namespace
+
+hipError_t launch_kminmers(uint64_t n_tiles, const uint64_t *tile_rec_off, const uint32_t *tile_cnt,
+                           const uint64_t *tile_goff, Records rec, const uint64_t *mn_off, const uint64_t *km_off,
+                           uint32_t k, uint64_t km_capacity, uint64_t *o_hash, uint32_t *o_start, uint32_t *o_end,
+                           uint8_t *o_rev, uint64_t mn_capacity, uint32_t *o_mn_j, uint32_t *o_mn_jend,
+                           uint32_t *o_mn_hash, uint64_t *xor_shards, const Counts *counts, hipStream_t st) {
+    if (n_tiles == 0) return hipSuccess;
+    dim3 g((unsigned)((n_tiles + KM_WAVES - 1) / KM_WAVES)), b(64 * KM_WAVES);
+    hipLaunchKernelGGL(kminmer_kernel, g, b, 0, st, n_tiles, tile_rec_off, tile_cnt, tile_goff, rec, mn_off, km_off, k,
+                       km_capacity, o_hash, o_start, o_end, o_rev, mn_capacity, o_mn_j, o_mn_jend, o_mn_hash, xor_shards, counts);
+    return hipGetLastError();
+}
+
+} // namespace s2k

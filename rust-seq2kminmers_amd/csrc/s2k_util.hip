@@ -1,0 +1,191 @@
+// s2k_util.hip -- small supporting kernels: exclusive scans over per-read / per-tile counts,
+// the synthetic base generator, and the final counts reduction.  None of these is hot: they touch
+// O(n_reads + n_tiles) words while the minimizer kernel touches O(n_bases) bytes.
+#include "s2k_dev.h"
+
+namespace s2k {
+
+namespace {
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ inline uint64_t scan_f(uint32_t x, uint32_t sub_k) {
+    // sub_k != 0: number of k-min-mers of a read with x minimizers = max(0, x-k+1) (src/lib.rs:235-261)
+    return sub_k ? (x >= sub_k ? (uint64_t)(x - sub_k + 1) : 0ull) : (uint64_t)x;
+}
+
+__device__ inline uint64_t block_reduce_sum(uint64_t v, uint64_t *sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    uint64_t t = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += sh[i];
+    return t; // valid in thread 0
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums(const uint32_t *__restrict__ in, uint64_t n,
+                                                                uint64_t *__restrict__ block_tmp, uint32_t sub_k) {
+    __shared__ uint64_t sh[SCAN_THREADS / 64];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK;
+    uint64_t s = 0;
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint64_t idx = base + (uint64_t)i * SCAN_THREADS + threadIdx.x;
+        if (idx < n) s += scan_f(in[idx], sub_k);
+    }
+    uint64_t t = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) block_tmp[blockIdx.x] = t;
+}
+
+// single block: in-place exclusive scan of block_tmp[0..nb), total -> block_tmp[nb]
+__global__ __launch_bounds__(1024) void scan_block_offsets(uint64_t *block_tmp, uint64_t nb) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < nb; base += 1024) {
+        uint64_t idx = base + threadIdx.x;
+        uint64_t v = idx < nb ? block_tmp[idx] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            uint64_t a = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += a;
+            __syncthreads();
+        }
+        uint64_t incl = sh[threadIdx.x];
+        uint64_t c = carry;
+        if (idx < nb) block_tmp[idx] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_tmp[nb] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_write(const uint32_t *__restrict__ in, uint64_t n,
+                                                           uint64_t *__restrict__ out,
+                                                           const uint64_t *__restrict__ block_tmp, uint64_t nb,
+                                                           uint32_t sub_k) {
+    __shared__ uint64_t sh[SCAN_THREADS];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint64_t idx = base + i;
+        v[i] = idx < n ? scan_f(in[idx], sub_k) : 0;
+        s += v[i];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < SCAN_THREADS; o <<= 1) {
+        uint64_t a = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += a;
+        __syncthreads();
+    }
+    uint64_t run = block_tmp[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint64_t idx = base + i;
+        if (idx < n) out[idx] = run;
+        run += v[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_tmp[nb];
+}
+
+__global__ void scan_empty(uint64_t *out) { out[0] = 0; }
+
+// ---- synthetic bases -------------------------------------------------------------------------
+__device__ inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// One thread = one aligned 16-base group (16 B store).  Uniform random ACGT like benches/bench.rs:19-31,
+// keyed by absolute base index so any sub-range reproduces (oracle: s2k_oracle_synth_bases).
+__global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *__restrict__ d) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // 16-base group relative to aligned start
+    uint64_t q0 = (first_base & ~15ull) + g * 16;
+    if (q0 >= first_base + n) return;
+    uint64_t z = splitmix64(seed ^ ((q0 >> 5) * 0xD6E8FEB86659FD93ULL));
+    uint32_t bits = (uint32_t)(z >> (2 * (q0 & 31)));
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint32_t code = (bits >> (2 * (4 * i + b))) & 3u;
+            uint32_t ch = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T';
+            x |= ch << (8 * b);
+        }
+        w[i] = x;
+    }
+    if (q0 >= first_base && q0 + 16 <= first_base + n && (((uintptr_t)(d + (q0 - first_base))) & 15) == 0) {
+        *reinterpret_cast<uint4 *>(d + (q0 - first_base)) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (int b = 0; b < 16; b++) {
+            uint64_t q = q0 + b;
+            if (q >= first_base && q < first_base + n) d[q - first_base] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(Counts *counts, const uint64_t *__restrict__ xor_shards,
+                                                       const uint64_t *mn_total, const uint64_t *km_total,
+                                                       uint64_t km_capacity, uint64_t mn_capacity) {
+    __shared__ uint64_t sh[4];
+    uint64_t x = 0;
+    for (int i = threadIdx.x; i < XOR_SHARDS; i += blockDim.x) x ^= xor_shards[i];
+    for (int o = 32; o > 0; o >>= 1) x ^= __shfl_down(x, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counts->xor_hash = sh[0] ^ sh[1] ^ sh[2] ^ sh[3];
+        counts->n_minimizers = *mn_total;
+        counts->n_kminmers = *km_total;
+        counts->km_overflow = (*km_total > km_capacity) ? 1u : 0u;
+        counts->mn_overflow = (mn_capacity != 0 && *mn_total > mn_capacity) ? 1u : 0u;
+    }
+}
+
+} // namespace
+
+size_t scan_tmp_bytes(uint64_t n) { return ((n + SCAN_BLOCK - 1) / SCAN_BLOCK + 2) * sizeof(uint64_t); }
+
+hipError_t launch_scan_u32(const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *block_tmp, uint32_t sub_k,
+                           hipStream_t st) {
+    if (n == 0) {
+        hipLaunchKernelGGL(scan_empty, dim3(1), dim3(1), 0, st, out);
+        return hipGetLastError();
+    }
+    uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, block_tmp, sub_k);
+    hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(1024), 0, st, block_tmp, nb);
+    hipLaunchKernelGGL(scan_write, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, out, block_tmp, nb, sub_k);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint64_t groups = ((first_base + n + 15) >> 4) - (first_base >> 4);
+    uint64_t blocks = (groups + 255) / 256;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, first_base, n, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(Counts *counts, const uint64_t *xor_shards, const uint64_t *mn_total, const uint64_t *km_total,
+                           uint64_t km_capacity, uint64_t mn_capacity, hipStream_t st) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, counts, xor_shards, mn_total, km_total, km_capacity,
+                       mn_capacity);
+    return hipGetLastError();
+}
+
+} // namespace s2k

@@ -1,0 +1,64 @@
+"""CPU tier: the C-ABI library loads and exports exactly what include/s2k.h declares; host-only entry
+points behave; nothing computes without a GPU (there is no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from s2k_loader import import_package
+
+pkg = import_package()
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "s2k.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(s2k_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = pkg.load_library()
+    declared = _header_functions()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), "include/s2k.h declares %s but libs2k.so does not export it" % name
+    assert sorted(pkg.ABI_SYMBOLS) == declared
+    assert lib.s2k_abi_version() == 1
+
+
+def test_hash_bound_host_function(oracle):
+    for d in (0.01, 0.001, 1e-4, 0.1, 0.5, 1.0, 3.0, 0.0, -2.0, float("nan"), 0.2, 1e-9, 0.999999):
+        assert pkg.hash_bound(d) == oracle.hash_bound(d)
+
+
+def test_strerror():
+    lib = pkg.load_library()
+    assert lib.s2k_strerror(0) == b"ok"
+    assert b"no GPU" in lib.s2k_strerror(8)
+
+
+def test_no_cpu_fallback_without_gpu():
+    lib = pkg.load_library()
+    if lib.s2k_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(pkg.S2kError) as e:
+        pkg.Engine(0)
+    assert e.value.status == 8  # S2K_ERR_NO_DEVICE
+
+
+def test_struct_layouts_match_header():
+    # field order / sizes of the ctypes mirrors against the C header (checked through sizeof on this ABI)
+    assert ctypes.sizeof(pkg.Params) == 24
+    assert ctypes.sizeof(pkg.Counts) == 48
+    assert ctypes.sizeof(pkg.DeviceOut) == 88
+    assert ctypes.sizeof(pkg.Result) == 96 + 48 + 8
+
+
+def test_kminmerhash_semantics():
+    a = pkg.KminmerHash.new_from_hash(5, 1, 2, 0, False)
+    b = pkg.KminmerHash(5, 9, 9, 3, True)
+    assert a == b and not (a < b)  # equality by hash only, src/kminmer.rs:181-185
+    assert a.get_hash() == 5
+    assert "rev: false" in repr(a)

@@ -1,0 +1,268 @@
+"""GPU tier: the HIP path, called through the C ABI, against the CPU oracle -- bit-exact hashes,
+k-min-mer tuples and original-space positions -- plus size-independent properties at
+larger sizes.  Mirrors tests/main.rs of the reference: KATs first, then cross-checks over an (l,k) grid."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+from gpu_util import OMODE, compare, pkg, rand_read
+
+pytestmark = pytest.mark.gpu
+HM = pkg.HashMode
+SCALAR = (HM.Regular, HM.Hpc)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = pkg.Engine(0)
+    yield e
+    e.close()
+
+
+def test_G1_reference_kat(eng, ecoli):
+    """tests/main.rs:41-57,60-73 through the reference-shaped iterator."""
+    kat = json.load(open(os.path.join(GOLD, "ref_kat.json")))["G1"]
+    it = pkg.KminmersIterator.new(ecoli, kat["l"], kat["k"], kat["density"], HM.Regular, engine=eng)
+    items = list(it)
+    assert [x.get_hash() for x in items] == kat["hashes32"]
+    assert [x.offset for x in items] == list(range(15))
+    assert (items[0].start, items[0].end, items[0].rev) == (2341, 9477, True)
+
+
+def test_ecoli_checkpoints(eng, oracle, ecoli):
+    ck = json.load(open(os.path.join(GOLD, "ecoli_checkpoints.json")))
+    for c in ck["configs"]:
+        mode = HM.Regular if c["mode"] == "regular" else HM.Hpc
+        for serial in (False, True):
+            got = compare(eng, oracle, [ecoli], c["l"], c["k"], c["density"], mode, force_serial=serial, tag="ecoli")
+            assert got["n"] == c["n_kminmers"] and got["n_minimizers"] == c["n_minimizers"]
+            assert got["counts"]["xor_hash"] == c["xor_hash"]
+            assert int(got["start"].astype(np.uint64).sum()) == c["sum_start"]
+            assert int(got["end"].astype(np.uint64).sum()) == c["sum_end"]
+
+
+def test_G4_mode_grid(eng, oracle, ecoli):
+    """tests/main.rs:82-89: Regular == Simd and Hpc == HpcSimd (hash-only equality) over the (l,k) grid."""
+    for l in (5, 7, 11, 17, 25, 31):
+        for k in (2, 5, 8):
+            r = {m: eng.extract_reads([ecoli], l, k, 0.01, m) for m in HM}
+            assert (r[HM.Regular]["hash"] == r[HM.Simd]["hash"]).all() and r[HM.Regular]["n"] == r[HM.Simd]["n"]
+            assert (r[HM.Hpc]["hash"] == r[HM.HpcSimd]["hash"]).all() and r[HM.Hpc]["n"] == r[HM.HpcSimd]["n"]
+            for m in HM:
+                ref = oracle.kminmers(ecoli, l, k, 0.01, OMODE[m])
+                assert (r[m]["hash"] == ref["hash"]).all() and (r[m]["start"] == ref["start"]).all()
+                assert (r[m]["end"] == ref["end"]).all() and (r[m]["rev"] == ref["rev"]).all()
+
+
+def test_committed_cases_single_and_batched(eng, oracle):
+    cases = json.load(open(os.path.join(GOLD, "derived_cases.json")))["cases"]
+    groups = {}
+    for c in cases:
+        mode = {"regular": HM.Regular, "hpc": HM.Hpc, "simd": HM.Simd, "hpcsimd": HM.HpcSimd}[c["mode"]]
+        seq = bytes.fromhex(c["seq_hex"])
+        got = eng.extract_reads([seq], c["l"], c["k"], c["density"], mode, want_minimizers=True)
+        for f in ("hash", "start", "end", "rev"):
+            assert [int(x) for x in got[f]] == c["kminmers"][f], (c["name"], c["mode"], f)
+        assert [int(x) for x in got["mn_j"]] == c["minimizers"]["j"], (c["name"], c["mode"])
+        assert [int(x) for x in got["mn_jend"]] == c["minimizers"]["jend"], (c["name"], c["mode"])
+        assert [int(x) for x in got["mn_hash"]] == c["minimizers"]["hash"], (c["name"], c["mode"])
+        groups.setdefault((mode, c["l"], c["k"], c["density"]), []).append(seq)
+    # the same reads concatenated into batches (reads of very different lengths share tiles)
+    for (mode, l, k, d), reads in groups.items():
+        compare(eng, oracle, reads, l, k, d, mode, tag="batched-cases")
+        if mode in SCALAR:
+            compare(eng, oracle, reads, l, k, d, mode, force_serial=True, expect_path=1, tag="batched-cases-serial")
+
+
+def test_ragged_batches_all_tile_alignments(eng, oracle):
+    """Read boundaries at every interesting offset relative to the 9216-base tiles and the 144-base lane
+    chunks; empty reads; reads of length l, l+1; reads spanning several tiles."""
+    rng = np.random.default_rng(42)
+    T = 9216
+    lens = [0, 1, 30, 31, 32, 33, 143, 144, 145, 0, 0, 5000, T - 5200 - 589, 1, T, T + 1, T - 1, 31, 2 * T + 7, 3, 17, T - 31,
+            T - 30, 31, 62, 0, 20000, 288, 289, 9000, 100, 40000, 15, 16, 144 * 3]
+    for hp, odd in ((0.0, 0.0), (0.3, 0.02)):
+        reads = [rand_read(rng, n, hp=hp, odd=odd) for n in lens]
+        for mode in SCALAR:
+            compare(eng, oracle, reads, 31, 10, 0.01, mode, expect_path=0, tag="ragged")
+            compare(eng, oracle, reads, 31, 3, 0.05, mode, expect_path=0, tag="ragged")
+            compare(eng, oracle, reads, 31, 10, 0.01, mode, force_serial=True, expect_path=1, tag="ragged-serial")
+
+
+def test_l_grid_dynamic_and_static_paths(eng, oracle):
+    rng = np.random.default_rng(7)
+    reads = [rand_read(rng, int(n), hp=0.25, odd=0.01) for n in rng.integers(0, 30000, size=24)]
+    for l in (1, 2, 4, 5, 7, 10, 11, 17, 25, 28, 31, 32, 33, 47, 64):
+        for mode in SCALAR:
+            compare(eng, oracle, reads, l, 5, 0.02, mode, expect_path=0, tag="lgrid")
+    for l in (65, 100, 255):  # beyond the tiled kernel: serial path
+        for mode in SCALAR:
+            compare(eng, oracle, reads[:8], l, 3, 0.05, mode, expect_path=1, tag="lgrid-long")
+
+
+def test_k_range(eng, oracle):
+    rng = np.random.default_rng(8)
+    reads = [rand_read(rng, int(n), hp=0.2) for n in (50000, 20, 9000, 12345, 70000)]
+    for k in (1, 2, 10, 31, 64, 65, 66, 100, 300):
+        for mode in SCALAR:
+            compare(eng, oracle, reads, 31, k, 0.02, mode, tag="krange")
+
+
+def test_density_extremes_and_pool_retry(eng, oracle):
+    rng = np.random.default_rng(9)
+    reads = [rand_read(rng, int(n), hp=0.2) for n in (30000, 100, 9216, 18432, 5)]
+    for d in (0.0, 1e-6, 0.3, 0.9, 1.0, 2.0):
+        for mode in SCALAR:
+            compare(eng, oracle, reads, 31, 4, d, mode, tag="density")
+    # low-complexity read: every position of a long poly-A-free repeat passes -> far more minimizers
+    # than the density predicts, the record pool must grow transparently
+    rep = (b"ACGTTGCA" * 6000)
+    h = oracle.nthash32_all(rep[:200], 31)
+    d = (int(h.min()) + 0.5) / 4294967295.0
+    for mode in SCALAR:
+        compare(eng, oracle, [rep, rand_read(rng, 20000)], 31, 5, d, mode, tag="low-complexity")
+
+
+def test_long_homopolymers_exceed_any_fixed_halo(eng, oracle):
+    """Runs of 300 .. 30000 equal bases: the l run heads after a tile lie arbitrarily far to the right."""
+    rng = np.random.default_rng(10)
+    parts = []
+    for run in (300, 3000, 9216, 9217, 30000, 700):
+        parts.append(rand_read(rng, int(rng.integers(20, 4000)), hp=0.2))
+        parts.append(bytes([rng.choice(list(b"ACGT"))]) * run)
+    parts.append(rand_read(rng, 5000, hp=0.2))
+    one = b"".join(parts)
+    reads = [one, b"A" * 50000, rand_read(rng, 3000), b"C" * 9216 + b"G" * 9216 + rand_read(rng, 100), one[::-1]]
+    for mode in SCALAR:
+        compare(eng, oracle, reads, 31, 5, 0.05, mode, expect_path=0, tag="homopolymers")
+        compare(eng, oracle, reads, 7, 2, 0.5, mode, expect_path=0, tag="homopolymers")
+
+
+def test_odd_bytes(eng, oracle):
+    rng = np.random.default_rng(11)
+    base = rand_read(rng, 30000, hp=0.2, odd=0.05)
+    compare(eng, oracle, [base, base.lower(), base[:100]], 31, 5, 0.05, HM.Regular, expect_path=0, tag="odd")
+    compare(eng, oracle, [base, base.lower(), base[:100]], 31, 5, 0.05, HM.Hpc, expect_path=0, tag="odd")
+    # bytes >= 0x80: Regular tiles take them (seed 1); Hpc tiles use bit 7 as the read-start mark and
+    # hand the call to the exact serial kernels
+    hi = bytearray(base)
+    for i in range(0, len(hi), 997):
+        hi[i] = 0x80 | (hi[i] & 0x7F)
+    hi[5000:5040] = bytes([0xC1]) * 40
+    reads = [bytes(hi), rand_read(rng, 12000)]
+    compare(eng, oracle, reads, 31, 5, 0.05, HM.Regular, expect_path=0, tag="hibit")
+    compare(eng, oracle, reads, 31, 5, 0.05, HM.Hpc, expect_path=1, tag="hibit")
+
+
+def test_simd_result_semantics(eng, oracle):
+    """SURVEY.md 8a traps (i)-(vi): strict '<', f32 bound, kept last l-mer, start-of-run end, low-nibble
+    seeds, dropped final 16-block when #l-mers % 16 == 0."""
+    rng = np.random.default_rng(12)
+    reads = [rand_read(rng, int(n), hp=0.3, odd=0.05) for n in (0, 10, 31, 46, 47, 62, 63, 64, 1000, 20000, 31 + 16 * 9 - 1)]
+    for mode in (HM.Simd, HM.HpcSimd):
+        for l in (4, 9, 16, 31):
+            for d in (0.02, 0.33, 1.0):
+                compare(eng, oracle, reads, l, 3, d, mode, expect_path=1, tag="simd")
+
+
+def test_status_codes(eng):
+    lib = eng.lib
+    b, off = pkg.pack_reads([b"ACGT" * 100])
+    for (l, k, mode, want) in ((0, 5, 0, 2), (256, 5, 0, 2), (31, 0, 0, 3), (31, 5000, 0, 3), (32, 5, 2, 2), (31, 5, 7, 1)):
+        with pytest.raises(pkg.S2kError) as e:
+            eng.extract(b, off, l, k, 0.1, mode)
+        assert e.value.status == want, (l, k, mode)
+    with pytest.raises(pkg.S2kError) as e:
+        eng.extract(b, np.array([0, 300, 200], dtype=np.uint64), 31, 5, 0.1, 0)
+    assert e.value.status == 1
+    assert eng.extract(b, off, 31, 5, 0.1, 0)["n"] >= 0  # the context stays usable after errors
+
+
+def test_device_api_capacity_and_async(eng, oracle):
+    import torch
+
+    rng = np.random.default_rng(13)
+    reads = [rand_read(rng, 10000) for _ in range(50)]
+    bases, off = pkg.pack_reads(reads)
+    dev = torch.device("cuda", 0)
+    d_b = torch.from_numpy(bases).to(dev)
+    d_o = torch.from_numpy(off.astype(np.int64)).to(dev)
+    ref = oracle.batch(bases, off, 31, 10, 0.01, 0)
+    nk = ref["n"]
+
+    def mk(cap):
+        t = {"km_off": torch.zeros(len(reads) + 1, dtype=torch.int64, device=dev), "hash": torch.zeros(max(cap, 1), dtype=torch.int64, device=dev),
+             "start": torch.zeros(max(cap, 1), dtype=torch.int32, device=dev), "end": torch.zeros(max(cap, 1), dtype=torch.int32, device=dev),
+             "rev": torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)}
+        o = pkg.DeviceOut()
+        o.km_capacity = cap
+        o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+        return t, o
+
+    torch.cuda.synchronize()
+    t, o = mk(nk // 2)
+    with pytest.raises(pkg.S2kError) as e:
+        eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), len(bases), 31, 10, 0.01, 0, o)
+    assert e.value.status == 7  # S2K_ERR_CAPACITY
+    # entries below the capacity are still correct, nothing was written past it
+    assert (t["hash"].cpu().numpy().view(np.uint64)[: nk // 2] == ref["hash"][: nk // 2]).all()
+    t, o = mk(nk)
+    eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), len(bases), 31, 10, 0.01, 0, o, sync=False)
+    c = eng.sync()
+    assert c["n_kminmers"] == nk and c["path"] == 0
+    assert (t["hash"].cpu().numpy().view(np.uint64) == ref["hash"]).all()
+    assert (t["km_off"].cpu().numpy().view(np.uint64) == ref["km_off"]).all()
+    assert (t["start"].cpu().numpy().view(np.uint32) == ref["start"]).all()
+    assert (t["rev"].cpu().numpy() == ref["rev"]).all()
+    # unaligned base pointer -> serial path, same answer
+    d_b2 = torch.zeros(len(bases) + 1, dtype=torch.uint8, device=dev)
+    d_b2[1:] = d_b
+    torch.cuda.synchronize()
+    t, o = mk(nk)
+    c = eng.extract_device(d_b2.data_ptr() + 1, d_o.data_ptr(), len(reads), len(bases), 31, 10, 0.01, 0, o)
+    assert c["path"] == 1 and (t["hash"].cpu().numpy().view(np.uint64) == ref["hash"]).all()
+
+
+def test_synth_generator_matches_oracle(eng, oracle):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    for (seed, first, n) in ((1, 0, 100000), (5, 12345, 70001), (9, 31, 17), (2, 16, 64)):
+        d = torch.zeros(n + 32, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.synth_bases_device(seed, first, n, d.data_ptr())
+        eng.lib.s2k_sync(eng.ctx, None)
+        got = d.cpu().numpy()
+        assert (got[:n] == oracle.synth_bases(seed, first, n)).all()
+        assert (got[n:] == 0).all()
+
+
+def test_standalone_hpc(eng, oracle, ecoli):
+    """tests/main.rs:76-78 equivalent for the GPU op."""
+    s, p = pkg.encode_rle_simd(ecoli, engine=eng)
+    rs, rp = oracle.hpc(ecoli, 2)
+    assert s == rs and (p == rp).all() and len(s) == 72873
+    assert pkg.hpc(b"AACCCGTTTTT", engine=eng) == b"ACGT"
+
+
+def test_synthetic_config2_sample_properties(eng, oracle):
+    """BASELINE config 2 shape (10 kbp uniform reads, l=31 k=10 d=0.01) at a size the oracle finishes in
+    seconds: full comparison, and tiled == serial."""
+    n_reads, L = 400, 10000
+    bases = oracle.synth_bases(1, 0, n_reads * L)
+    off = (np.arange(n_reads + 1, dtype=np.uint64) * L)
+    for mode in SCALAR:
+        a = eng.extract(bases, off, 31, 10, 0.01, mode)
+        b = eng.extract(bases, off, 31, 10, 0.01, mode, force_serial=True)
+        ref = oracle.batch(bases, off, 31, 10, 0.01, OMODE[mode], threads=8)
+        for f in ("km_off", "hash", "start", "end", "rev"):
+            assert (a[f] == ref[f]).all() and (b[f] == ref[f]).all(), (mode, f)
+        assert a["counts"]["path"] == 0 and b["counts"]["path"] == 1
+        # properties: sorted starts within a read, start <= end, offsets are dense
+        for r in range(0, n_reads, 37):
+            s, e = int(a["km_off"][r]), int(a["km_off"][r + 1])
+            assert (np.diff(a["start"][s:e].astype(np.int64)) > 0).all()
+            assert (a["end"][s:e] > a["start"][s:e]).all() and int(a["end"][s:e].max(initial=0)) < L
