@@ -81,6 +81,13 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 and the system ROCm has
+    # another; whichever is mapped first serves both (same SONAME).  Import torch first so that device
+    # memory and streams handed over by torch belong to the runtime this library talks to.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise ImportError("%s is missing: build it with `make -C %s` (or __graft_entry__.build())" % (p, os.path.dirname(p)))
     L = C.CDLL(p)

@@ -69,17 +69,21 @@ __global__ __launch_bounds__(64 * KM_WAVES) void kminmer_kernel(
         const uint64_t g = g0 + i;
         if (lds_path) {
             wave_sync(); // LDS rows are wave-private: order this round's writes after the previous round's reads
-            s_x[w][lane] = mix32(hv);
-            s_je[w][lane] = je;
-            // entries 64 .. 64+k-2 : records that follow this round's 64
-            for (uint32_t e = 64 + lane; e < 64 + k - 1; e += 64) {
-                Cursor c{t, (uint64_t)base + e};
+            // window entry e <-> record (base + e) counted from this tile's first record; entries past the
+            // tile's own records continue in the following tiles (the global sequence is contiguous)
+            for (uint32_t e = lane; e < 64 + k - 1; e += 64) {
                 uint64_t x = 0;
                 uint32_t jj = 0;
-                if (normalize(c, tile_cnt, n_tiles)) {
-                    uint64_t a = tile_rec_off[c.tile] + c.idx;
-                    x = mix32(rec.hash[a]);
-                    jj = rec.jend[a];
+                if (e < 64 && have) {
+                    x = mix32(hv);
+                    jj = je;
+                } else {
+                    Cursor c{t, (uint64_t)base + e};
+                    if (normalize(c, tile_cnt, n_tiles)) {
+                        uint64_t a = tile_rec_off[c.tile] + c.idx;
+                        x = mix32(rec.hash[a]);
+                        jj = rec.jend[a];
+                    }
                 }
                 s_x[w][e] = x;
                 s_je[w][e] = jj;
