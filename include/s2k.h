@@ -159,6 +159,9 @@ s2k_status s2k_synth_bases_device(s2k_ctx *ctx, uint64_t seed, uint64_t first_ba
  * context's stream: which: 0 = whole pipeline, 1 = the minimizer kernel (dominant), 2 = k-min-mer kernel. */
 s2k_status s2k_last_kernel_ms(s2k_ctx *ctx, int which, float *ms);
 s2k_status s2k_enable_timing(s2k_ctx *ctx, int on);
+/* Sum over every s2k_extract_device call since s2k_enable_timing(ctx, 1) of the same HIP-event
+ * durations (`which` as above), and the number of calls: average kernel duration over a timed region. */
+s2k_status s2k_timing_total(s2k_ctx *ctx, int which, double *ms_sum, uint32_t *n_calls);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libs2k.so")
 ABI_SYMBOLS = [
     "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_strerror",
     "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
-    "s2k_hpc_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing",
+    "s2k_hpc_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total",
 ]
 
 
@@ -115,6 +115,7 @@ def load_library(path=None):
     L.s2k_synth_bases_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
     L.s2k_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.s2k_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    L.s2k_timing_total.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     if path is None:
         _lib = L
     return L
@@ -179,6 +180,12 @@ class Engine:
         ms = C.c_float(0)
         self._check(self.lib.s2k_last_kernel_ms(self.ctx, which, C.byref(ms)))
         return float(ms.value)
+
+    def timing_total(self, which):
+        """(sum of HIP-event ms, n_calls) since enable_timing(True); which: 0 pipeline, 1 minimizer kernel, 2 k-min-mer kernel"""
+        ms, n = C.c_double(0), C.c_uint32(0)
+        self._check(self.lib.s2k_timing_total(self.ctx, which, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     # ---- host-buffer API (s2k_extract) ---------------------------------------------------------------
     def extract(self, bases, read_off, l, k, density, mode=HashMode.Hpc, want_minimizers=False, force_serial=False):

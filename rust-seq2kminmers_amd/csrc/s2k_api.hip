@@ -80,7 +80,9 @@ struct s2k_ctx {
     Counts *d_counts = nullptr;
     Counts *h_counts = nullptr; // pinned
     uint64_t *d_xor = nullptr;
-    hipEvent_t ev[6]{};
+    std::vector<hipEvent_t> evs; // 6 events per timed call, in call order since timing was enabled
+    size_t ev_used = 0;           // sets handed out
+    hipEvent_t *ev = nullptr;     // set of the current / last call
     bool timing = false, timed = false;
     Call call;
     bool pending = false;
@@ -217,7 +219,18 @@ s2k_status enqueue(s2k_ctx *ctx) {
 
     const bool tm = ctx->timing;
     ctx->timed = tm;
-    if (tm) S2K_TRY(hipEventRecord(ctx->ev[0], st), "event");
+    if (tm) {
+        if (ctx->evs.size() < (ctx->ev_used + 1) * 6) {
+            for (int i = 0; i < 6; i++) {
+                hipEvent_t e;
+                S2K_TRY(hipEventCreate(&e), "event create");
+                ctx->evs.push_back(e);
+            }
+        }
+        ctx->ev = &ctx->evs[ctx->ev_used * 6];
+        ctx->ev_used++;
+        S2K_TRY(hipEventRecord(ctx->ev[0], st), "event");
+    }
     S2K_TRY(hipMemsetAsync(ctx->d_counts, 0, sizeof(Counts), st), "memset counts");
     S2K_TRY(hipMemsetAsync(ctx->d_xor, 0, XOR_SHARDS * sizeof(uint64_t), st), "memset xor");
     S2K_TRY(hipMemsetAsync(pool_cursor, 0, 4 * sizeof(uint64_t), st), "memset cursor");
@@ -349,7 +362,6 @@ s2k_ctx *s2k_create(int device, s2k_status *status) {
     ok = ok && hipMalloc((void **)&ctx->d_counts, sizeof(Counts)) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_xor, XOR_SHARDS * sizeof(uint64_t)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_counts, sizeof(Counts), hipHostMallocDefault) == hipSuccess;
-    for (int i = 0; ok && i < 6; i++) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
     if (!ok) {
         *status = S2K_ERR_DEVICE;
         s2k_destroy(ctx);
@@ -371,8 +383,7 @@ void s2k_destroy(s2k_ctx *ctx) {
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
     if (ctx->d_xor) (void)hipFree(ctx->d_xor);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
-    for (int i = 0; i < 6; i++)
-        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (hipEvent_t e : ctx->evs) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -392,12 +403,32 @@ s2k_status s2k_set_stream(s2k_ctx *ctx, void *hip_stream) {
 s2k_status s2k_enable_timing(s2k_ctx *ctx, int on) {
     if (!ctx) return S2K_ERR_INVALID_ARG;
     ctx->timing = on != 0;
+    ctx->ev_used = 0; // restart the per-call event log
+    ctx->timed = false;
+    return S2K_OK;
+}
+
+s2k_status s2k_timing_total(s2k_ctx *ctx, int which, double *ms_sum, uint32_t *n_calls) {
+    if (!ctx || !ms_sum || !n_calls || which < 0 || which > 2) return S2K_ERR_INVALID_ARG;
+    if (ctx->pending) {
+        s2k_status st = finish(ctx, nullptr);
+        if (st != S2K_OK && st != S2K_ERR_CAPACITY) return st;
+    }
+    int a = which == 0 ? 0 : which == 1 ? 1 : 3, b = which == 0 ? 5 : which == 1 ? 2 : 4;
+    double sum = 0;
+    for (size_t i = 0; i < ctx->ev_used; i++) {
+        float ms = 0;
+        S2K_TRY(hipEventElapsedTime(&ms, ctx->evs[i * 6 + a], ctx->evs[i * 6 + b]), "event elapsed");
+        sum += ms;
+    }
+    *ms_sum = sum;
+    *n_calls = (uint32_t)ctx->ev_used;
     return S2K_OK;
 }
 
 s2k_status s2k_last_kernel_ms(s2k_ctx *ctx, int which, float *ms) {
     if (!ctx || !ms || which < 0 || which > 2) return S2K_ERR_INVALID_ARG;
-    if (!ctx->timed) return fail(ctx, S2K_ERR_INVALID_ARG, "timing was not enabled for the last call");
+    if (!ctx->timed || !ctx->ev) return fail(ctx, S2K_ERR_INVALID_ARG, "timing was not enabled for the last call");
     if (ctx->pending) {
         s2k_status st = finish(ctx, nullptr);
         if (st != S2K_OK && st != S2K_ERR_CAPACITY) return st;
