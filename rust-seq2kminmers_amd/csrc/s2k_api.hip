@@ -66,7 +66,8 @@ struct Call { // everything needed to (re-)enqueue one extraction
     Sem sem{};
     uint32_t bound = 0;
     bool serial = false;
-    uint64_t pool_cap = 0;
+    uint64_t pool_cap = 0; // serial: dense record capacity; tiled: capacity of the overflow region
+    uint64_t slab_cap = 0; // tiled: records per tile slab
     bool valid = false;
 };
 
@@ -170,6 +171,22 @@ uint64_t pool_estimate(uint64_t n_bases, uint64_t n_units, double density, bool 
     return cap;
 }
 
+// records per tile slab: mean + 6 sigma of a binomial(TILE_BASES, p) + margin
+uint64_t slab_estimate(double density) {
+    double d = density < 0 ? 0 : (density > 1 ? 1 : density);
+    double mu = (double)TILE_BASES * (1.0 - (1.0 - d) * (1.0 - d));
+    uint64_t cap = (uint64_t)(mu + 6.0 * sqrt(mu + 1.0)) + 32;
+    cap = (cap + 15) & ~(uint64_t)15;
+    if (cap > (uint64_t)TILE_BASES) cap = TILE_BASES;
+    return cap;
+}
+// overflow region of the tiled path: 2 % of the expected records, at least a few tiles' worth
+uint64_t overflow_estimate(uint64_t n_bases, double density) {
+    double d = density < 0 ? 0 : (density > 1 ? 1 : density);
+    double p = 1.0 - (1.0 - d) * (1.0 - d);
+    return (uint64_t)((double)n_bases * p * 0.02) + 4 * (uint64_t)TILE_BASES;
+}
+
 bool tiled_supported(const Sem &s) {
     // the tiled kernel implements the two scalar HashModes (the parity target); the Simd result
     // semantics run on the serial kernels
@@ -201,11 +218,14 @@ s2k_status enqueue(s2k_ctx *ctx) {
             tile_rec_off = a.take<uint64_t>(n_tiles + 1);
             tile_goff = a.take<uint64_t>(n_tiles + 1);
         }
-        rec.j = a.take<uint32_t>(c.pool_cap);
-        rec.jend = a.take<uint32_t>(c.pool_cap);
-        rec.hash = a.take<uint32_t>(c.pool_cap);
-        rec.rid = a.take<uint32_t>(c.pool_cap);
-        rec.capacity = c.pool_cap;
+        const uint64_t rec_total = c.serial ? c.pool_cap : n_tiles * c.slab_cap + c.pool_cap;
+        rec.j = a.take<uint32_t>(rec_total);
+        rec.jend = a.take<uint32_t>(rec_total);
+        rec.hash = a.take<uint32_t>(rec_total);
+        rec.rid = a.take<uint32_t>(rec_total);
+        rec.capacity = rec_total;
+        rec.slab_cap = c.serial ? 0 : c.slab_cap;
+        rec.ovf_base = c.serial ? 0 : n_tiles * c.slab_cap;
         if (pass == 0) {
             S2K_TRY(ctx->ws.ensure(a.off + 256), "workspace allocation");
             a.base = (char *)ctx->ws.p;
@@ -284,7 +304,7 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
             if (st != S2K_OK) return st;
             continue;
         }
-        if (h->pool_overflow) { // minimizer record pool was too small: re-run with the exact size
+        if (h->pool_overflow) { // record pool (serial) / overflow region (tiled) too small: re-run with the exact size
             c.pool_cap = h->pool_needed + h->pool_needed / 64 + (uint64_t)TILE_BASES + 4096;
             s2k_status st = enqueue(ctx);
             if (st != S2K_OK) return st;
@@ -294,6 +314,15 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
         h->n_bases = c.n_bases;
         h->hash_bound = c.bound;
         h->path = c.serial ? 1u : 0u;
+        if (c.sem.dbg_skip & 8) {
+            fprintf(stderr, "[s2k dbg] phase cycles (sum over waves):");
+            for (int i = 0; i < 8; i++) {
+                unsigned long long sum = 0;
+                for (int sh = 0; sh < 64; sh++) sum += h->dbg_cycles[sh][i];
+                fprintf(stderr, " %llu", sum);
+            }
+            fprintf(stderr, "\n");
+        }
         if (counts) memcpy(counts, h, sizeof(s2k_counts));
         ctx->pending_status = (h->km_overflow || h->mn_overflow) ? S2K_ERR_CAPACITY : S2K_OK;
         if (ctx->pending_status != S2K_OK) ctx->err = "device output capacity too small; see counts";
@@ -460,9 +489,11 @@ s2k_status s2k_extract_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64
     c.n_bases = n_bases;
     c.params = *params;
     c.out = *out;
+    if (const char *dbg = getenv("S2K_DEBUG_SKIP")) c.sem.dbg_skip = (uint32_t)atoi(dbg); // ablation timing only
     // the tiled kernel stages tiles with 16 B vector loads: it needs a 16 B aligned base pointer
     c.serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(c.sem) || (((uintptr_t)d_bases) & 15u) != 0;
-    c.pool_cap = pool_estimate(n_bases, c.serial ? n_reads : (n_bases + TILE_BASES - 1) / TILE_BASES, params->density, c.sem.hpc);
+    c.pool_cap = c.serial ? pool_estimate(n_bases, n_reads, params->density, c.sem.hpc) : overflow_estimate(n_bases, params->density);
+    c.slab_cap = slab_estimate(params->density);
     c.valid = true;
     ctx->pending_status = S2K_OK;
     st = enqueue(ctx);
@@ -505,7 +536,8 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
 
     const bool want_mn = params->flags & S2K_FLAG_WANT_MINIMIZERS;
     const bool serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(sem);
-    uint64_t cap = pool_estimate(n_bases, serial ? n_reads : (n_bases + TILE_BASES - 1) / TILE_BASES, params->density, sem.hpc);
+    uint64_t cap = pool_estimate(n_bases, n_reads, params->density, sem.hpc);
+    (void)serial;
     s2k_counts cnt;
     s2k_device_out o;
     for (int attempt = 0;; attempt++) {

@@ -51,6 +51,7 @@ struct Sem {
     uint32_t keep_last;  // Hpc scalar drops the last HPC l-mer (src/nthash_hpc.rs:265-267); others keep theirs
     uint32_t end_kind;   // 0: j+l-1 (lib.rs:202,226)  1: st[p+l]-1 (nthash_hpc.rs:281)  2: st[p+l-1] (nthash_hpc_simd.rs:64)
     uint32_t tail_quirk; // drop the final 16-block when #l-mers % 16 == 0 (src/nthash_avx512_32.rs:134-138)
+    uint32_t dbg_skip;   // timing ablations only (env S2K_DEBUG_SKIP; results are wrong when set): 1 hash loop, 2 dense phase, 4 hpc compaction
 };
 
 struct Counts { // mirrored by s2k_counts (include/s2k.h)
@@ -59,6 +60,7 @@ struct Counts { // mirrored by s2k_counts (include/s2k.h)
     // internal
     uint64_t pool_needed;
     uint32_t pool_overflow, non_ascii, km_overflow, mn_overflow;
+    uint64_t dbg_cycles[64][8]; // S2K_DEBUG_SKIP & 8: shader-clock cycles per phase, summed over waves
 };
 
 constexpr int XOR_SHARDS = 4096;
@@ -78,7 +80,12 @@ __device__ inline void wave_sync() {
 
 struct Records { // SoA pool of minimizer records written by the minimizer kernels
     uint32_t *j, *jend, *hash, *rid;
-    uint64_t capacity;
+    uint64_t capacity;  // total entries
+    // tiled kernel: tile t owns the fixed slab [t*slab_cap, (t+1)*slab_cap); a tile with more hits than
+    // that (low-complexity sequence) takes space from the shared overflow region [ovf_base, capacity)
+    // with one atomic.  A single shared cursor for every tile serialises the whole kernel (~88 atomics
+    // per microsecond on one address = 12 ms for 1.1 M tiles).
+    uint64_t slab_cap, ovf_base;
 };
 
 #define S2K_HIP_CHECK(expr)                                                      \

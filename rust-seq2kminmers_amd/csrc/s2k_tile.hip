@@ -29,45 +29,85 @@
 //    the exact serial kernels).
 #include "s2k_dev.h"
 
+#include <type_traits>
+
 namespace s2k {
 namespace {
 
-constexpr int TW = 2;                                  // waves per block
+constexpr int TW = 4;                                  // waves per block (they share the two seed tables)
 constexpr int HS_OFF = 16;                             // data starts here; byte HS_OFF-1 absorbs "slot -1" stores
 constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window slack
 constexpr int NPC = TILE_T / 8;                        // 18 capture pieces per lane
 constexpr int MAX_L_TILED = 64;
+constexpr int LISTCAP = 512;                           // hits handled per dense batch
+constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
 
-struct alignas(16) WaveLds {
+struct HpcLds {
+    uint32_t fm[64][5];      // run-head flags of the lane's 144 raw bytes, 32-byte groups, bit 8b+d <-> byte 4d+b
+    uint32_t hbase[64];      // exclusive prefix of per-lane run-head counts
+    uint32_t halo_pos[64];   // tile-relative raw offsets of the run heads that follow the tile
+};
+struct NoHpcLds {};
+
+template <bool HPC>
+struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
     uint8_t buf[BUF_BYTES];
     uint32_t caps[NPC][64];  // hash of the last hit of each 8-position piece
     uint32_t hm[64][5];      // raw hit masks, bit x = lane-local hash position x (stored bytewise)
-    uint32_t hoff[64];       // exclusive prefix of per-lane hit counts
-    uint32_t fm[64][5];      // Hpc: run-head flags of the lane's 144 raw bytes, 32-byte groups, bit 8b+d <-> byte 4d+b
-    uint32_t hbase[64];      // Hpc: exclusive prefix of per-lane run-head counts
-    uint32_t halo_pos[64];   // Hpc: tile-relative raw offsets of the run heads that follow the tile
+    uint16_t list[LISTCAP];  // validated hits of the current batch, tile-local hash positions, ascending
+    uint16_t jobx[64];       // hits whose hash must be re-derived: tile-local position ...
+    uint32_t jobslot[64];    // ... and record slot (relative to the tile's base)
+    int32_t hb[64];          // read starts inside the tile, as hash-space positions (ascending)
+    uint64_t rs[64];         // rs[i] = read_off[r0 + i]
 };
-struct BlockLds {
-    uint2 t_in[256];   // {h[c], rotl(rc[c], l-1)}
-    uint2 t_out[256];  // {rotl(h[c], l), rotr(rc[c], 1)}
-    WaveLds w[TW];
-};
-static_assert(sizeof(BlockLds) <= 64 * 1024, "static LDS limit");
+constexpr int TABLE_BYTES = 2 * 256 * 8; // t_in: {h[c], rotl(rc[c], l-1)}   t_out: {rotl(h[c], l), rotr(rc[c], 1)}
+template <bool HPC>
+constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>); }
+static_assert(2 * block_lds_bytes<true>() <= 160 * 1024, "two blocks per CU must fit the 160 KiB LDS");
 
+// inclusive scan over the 64 lanes with DPP row shifts / broadcasts (no LDS round trips)
 __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t u = __shfl_up(v, o);
-        if (lane >= o) v += u;
-    }
-    return v;
+    (void)lane;
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    uint32_t a = v + t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    a += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false); // row_shr:3
+    a += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x114, 0xf, 0xe, false); // row_shr:4, banks 1-3
+    a += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x118, 0xf, 0xc, false); // row_shr:8, banks 2-3
+    a += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+    a += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
+    a += t;
+    return a;
 }
+// XOR of v over the 64 lanes (returned in every lane): same DPP ladder as the scan, then lane 63's value
 __device__ inline uint32_t wave_xor(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o);
-    return v;
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    uint32_t a = v ^ t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    a ^= t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);
+    a ^= t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x114, 0xf, 0xe, false);
+    a ^= t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x118, 0xf, 0xc, false);
+    a ^= t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x142, 0xa, 0xf, false);
+    a ^= t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, false);
+    a ^= t;
+    return (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
 }
-__device__ inline uint32_t bcast(uint32_t v, int src) { return __shfl(v, src); }
+// value of lane `src` (wave-uniform index) in every lane: v_readlane, no LDS round trip
+__device__ inline uint32_t bcast(uint32_t v, int src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
+}
 
 // index of the n-th (0-based) set bit of w; n < popc(w)
 __device__ inline uint32_t select_nth_32(uint32_t w, uint32_t n) {
@@ -115,16 +155,58 @@ __host__ __device__ constexpr uint32_t at_or_before(int d, int b) {
 }
 
 __device__ inline uint32_t byte_of(const uint32_t *W, int idx) { return (W[idx >> 2] >> (8 * (idx & 3))) & 0xFFu; }
+// Seed-table lookups of the hot loop.  The two 2 KiB tables sit at LDS byte offsets 0 and 2048 (the kernel
+// has no static LDS, so the dynamic region starts at 0; checked at kernel entry).  The byte offset of an
+// entry is formed by ONE instruction -- v_lshlrev_b32_sdwa selects byte k of a window dword and shifts it
+// by 3 -- and the table base rides in the ds_read immediate.  Being inline asm, the offset is also opaque
+// to the optimizer: every base is looked up twice, 31 positions apart (entering and leaving the window),
+// and if the compiler saw one index it would fuse the two into a single ds_read2st64_b64 and keep the
+// second half alive for 31 positions (256 VGPRs, one wave per SIMD).
+typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+template <int BYTE>
+__device__ __forceinline__ uint32_t byte_x8(uint32_t w) {
+    uint32_t off;
+    if constexpr (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(3u), "v"(w));
+    if constexpr (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(3u), "v"(w));
+    if constexpr (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(3u), "v"(w));
+    if constexpr (BYTE == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(3u), "v"(w));
+    return off;
+}
+template <int IDX, int TABLE_OFF, int NW>
+__device__ __forceinline__ uint2 lut(const uint32_t (&W)[NW]) {
+    const uint32_t off = byte_x8<IDX & 3>(W[IDX >> 2]);
+    const unsigned long long v = *reinterpret_cast<lds_cu64 *>(off + TABLE_OFF); // ds_read_b64 v, off offset:TABLE_OFF
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+template <int N, int BASE, int TABLE_OFF, int NW, int J = 0>
+__device__ __forceinline__ void lut_row(uint2 *dst, const uint32_t (&W)[NW]) { // dst[j] = table[byte BASE+j], j < N
+    if constexpr (J < N) {
+        dst[J] = lut<BASE + J, TABLE_OFF>(W);
+        lut_row<N, BASE, TABLE_OFF, NW, J + 1>(dst, W);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Hash loop, compile-time l, NP 16-byte pieces per lane.  Lane q owns hash positions
 // [16*NP*q, 16*NP*(q+1)) of the byte array D (LDS).  Branch-free: per position
 //   hv = min(fh, rh); hit = hv <= bound; cap = hit ? hv : cap; bits = bits<<1 | hit; roll.
 // ------------------------------------------------------------------------------------------------
-template <int L, int NP>
-__device__ inline void hash_loop_static(const uint8_t *D, const uint2 *__restrict__ t_in,
-                                        const uint2 *__restrict__ t_out, uint32_t bound, int lane, WaveLds &S) {
-    constexpr int NWP = (L + 16 + 15) / 16; // pieces that must be resident to serve IN bytes of the current piece
+// One position of the hot loop.  The hit test, the capture of the hit's hash and the hit bit are three
+// VALU instructions chained through VCC (compare -> select -> add-with-carry shifts the bit in).
+__device__ __forceinline__ void hit_track(uint32_t hv, uint32_t bound, uint32_t &cap, uint32_t &bits) {
+    asm("v_cmp_ge_u32_e32 vcc, %2, %3\n\t"
+        "v_cndmask_b32_e32 %0, %0, %3, vcc\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+        : "+v"(cap), "+v"(bits)
+        : "s"(bound), "v"(hv)
+        : "vcc");
+}
+
+template <int L, int NP, class WL>
+__device__ __forceinline__ void hash_loop_static(const uint8_t *D, const uint2 *__restrict__ t_in,
+                                                 const uint2 *__restrict__ t_out, uint32_t bound, int lane, WL &S) {
+    // bytes [0, L+24) of the lane-relative stream must be resident while the NEXT half-piece's seeds are fetched
+    constexpr int NWP = (L + 24 + 15) / 16;
     uint32_t W[NWP * 4];
     const uint4 *src = reinterpret_cast<const uint4 *>(D + 16 * NP * lane);
 #pragma unroll
@@ -132,38 +214,50 @@ __device__ inline void hash_loop_static(const uint8_t *D, const uint2 *__restric
         uint4 v = src[p];
         W[4 * p] = v.x; W[4 * p + 1] = v.y; W[4 * p + 2] = v.z; W[4 * p + 3] = v.w;
     }
+    // seeds are fetched one 8-position half-piece ahead of their use, so that one LDS round trip is paid
+    // per 8 positions instead of per position (two waves per SIMD cannot hide a dependent ds_read per step)
+    uint2 sin[2][8], sout[2][8];
+    lut_row<8, L, 0>(sin[0], W);
+    lut_row<8, 0, 2048>(sout[0], W);
     uint32_t fh = 0, rh = 0;
+    {
+        uint2 wi[L];
+        lut_row<L, 0, 0>(wi, W);
 #pragma unroll
-    for (int i = 0; i < L; i++) { // warm-up: first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174)
-        uint2 ti = t_in[byte_of(W, i)];
-        fh = __builtin_rotateleft32(fh, 1) ^ ti.x;
-        rh = __builtin_rotateright32(rh, 1) ^ ti.y;
+        for (int i = 0; i < L; i++) { // warm-up: first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174)
+            fh = __builtin_rotateleft32(fh, 1) ^ wi[i].x;
+            rh = __builtin_rotateright32(rh, 1) ^ wi[i].y;
+        }
     }
-    uint32_t cap = 0, bits = 0;
+    uint32_t cap = 0;
     uint8_t *hmb = reinterpret_cast<uint8_t *>(S.hm[lane]);
 #pragma unroll
-    for (int m = 0; m < NP; m++) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            uint32_t hv = fh < rh ? fh : rh;      // canonical (src/nthash_hpc.rs:276)
-            bool hit = hv <= bound;               // src/nthash_hpc.rs:277 / src/lib.rs:228
-            cap = hit ? hv : cap;
-            bits = (bits << 1) | (hit ? 1u : 0u);
-            uint2 to = t_out[byte_of(W, j)];
-            uint2 ti = t_in[byte_of(W, L + j)];
-            fh = __builtin_rotateleft32(fh, 1) ^ to.x ^ ti.x;  // src/nthash_hpc.rs:245
-            rh = __builtin_rotateright32(rh, 1) ^ to.y ^ ti.y; // src/nthash_hpc.rs:247-249
-            if ((j & 7) == 7) {
-                const int pc = 2 * m + (j >> 3);
-                hmb[pc] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-                S.caps[pc][lane] = cap;
-                bits = 0;
+    for (int hp = 0; hp < 2 * NP; hp++) {
+        const int cur = hp & 1, nxt = cur ^ 1;
+        const int wo = 8 * (hp & 1); // offset of this half-piece inside the window (window starts at piece hp/2)
+        if (hp + 1 < 2 * NP) {
+            if (wo == 0) {
+                lut_row<8, 8 + L, 0>(sin[nxt], W);
+                lut_row<8, 8, 2048>(sout[nxt], W);
+            } else {
+                lut_row<8, 16 + L, 0>(sin[nxt], W);
+                lut_row<8, 16, 2048>(sout[nxt], W);
             }
         }
-        if (m + 1 < NP) { // slide the window by one piece
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t hv = fh < rh ? fh : rh;                      // canonical (src/nthash_hpc.rs:276)
+            hit_track(hv, bound, cap, bits);                      // hv <= bound (src/nthash_hpc.rs:277 / src/lib.rs:228)
+            fh = __builtin_rotateleft32(fh, 1) ^ sout[cur][j].x ^ sin[cur][j].x;  // src/nthash_hpc.rs:245
+            rh = __builtin_rotateright32(rh, 1) ^ sout[cur][j].y ^ sin[cur][j].y; // src/nthash_hpc.rs:247-249
+        }
+        hmb[hp] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
+        S.caps[hp][lane] = cap;
+        if ((hp & 1) && hp + 1 < 2 * NP) { // slide the window by one piece
 #pragma unroll
             for (int i = 0; i < (NWP - 1) * 4; i++) W[i] = W[i + 4];
-            uint4 v = src[m + NWP];
+            uint4 v = src[(hp >> 1) + NWP];
             W[4 * NWP - 4] = v.x; W[4 * NWP - 3] = v.y; W[4 * NWP - 2] = v.z; W[4 * NWP - 1] = v.w;
         }
     }
@@ -171,8 +265,9 @@ __device__ inline void hash_loop_static(const uint8_t *D, const uint2 *__restric
 
 // Same loop for a run-time l (1..64): bytes are fetched one by one from LDS.  Slower; only l values
 // without a static instantiation come here.
-__device__ inline void hash_loop_dynamic(const uint8_t *D, const uint2 *__restrict__ t_in,
-                                         const uint2 *__restrict__ t_out, uint32_t bound, int lane, WaveLds &S,
+template <class WL>
+__device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 *__restrict__ t_in,
+                                         const uint2 *__restrict__ t_out, uint32_t bound, int lane, WL &S,
                                          uint32_t l, int np) {
     const uint8_t *q = D + 16 * np * lane;
     uint32_t fh = 0, rh = 0;
@@ -200,16 +295,22 @@ __device__ inline void hash_loop_dynamic(const uint8_t *D, const uint2 *__restri
     }
 }
 
-template <int L>
-__device__ inline void hash_stage(const uint8_t *D, const uint2 *t_in, const uint2 *t_out, uint32_t bound, int lane,
-                                  WaveLds &S, uint32_t l, int np) {
+// Everything below is force-inlined into the kernel so that the LDS operands keep their address space
+// (a generic pointer costs a 64-bit add, a null compare and a select per table lookup).
+template <int L, bool HPC, class WL>
+__device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *t_in, const uint2 *t_out, uint32_t bound,
+                                           int lane, WL &S, uint32_t l, int np) {
     if constexpr (L > 0) {
-        switch (np) { // wave-uniform
-        case 1: hash_loop_static<L, 1>(D, t_in, t_out, bound, lane, S); break;
-        case 3: hash_loop_static<L, 3>(D, t_in, t_out, bound, lane, S); break;
-        case 5: hash_loop_static<L, 5>(D, t_in, t_out, bound, lane, S); break;
-        case 7: hash_loop_static<L, 7>(D, t_in, t_out, bound, lane, S); break;
-        default: hash_loop_static<L, 9>(D, t_in, t_out, bound, lane, S); break;
+        if constexpr (!HPC) {
+            hash_loop_static<L, 9>(D, t_in, t_out, bound, lane, S); // raw tiles always span 9 pieces per lane
+        } else {
+            switch (np) { // wave-uniform: the compacted tile is shorter than the raw one
+            case 1: hash_loop_static<L, 1>(D, t_in, t_out, bound, lane, S); break;
+            case 3: hash_loop_static<L, 3>(D, t_in, t_out, bound, lane, S); break;
+            case 5: hash_loop_static<L, 5>(D, t_in, t_out, bound, lane, S); break;
+            case 7: hash_loop_static<L, 7>(D, t_in, t_out, bound, lane, S); break;
+            default: hash_loop_static<L, 9>(D, t_in, t_out, bound, lane, S); break;
+            }
         }
     } else {
         hash_loop_dynamic(D, t_in, t_out, bound, lane, S, l, np);
@@ -221,17 +322,24 @@ __device__ inline void hash_stage(const uint8_t *D, const uint2 *t_in, const uin
 // the tile) and leaves D[0..R_t) = head bytes, D[R_t..R_t+halo_n) = following heads, S.fm / S.hbase /
 // S.halo_pos for the back-map.  `na` accumulates bytes with bit 7 set.
 // ------------------------------------------------------------------------------------------------
-__device__ inline uint32_t hpc_compact(uint8_t *D, WaveLds &S, const uint8_t *__restrict__ bases,
-                                       const uint64_t *__restrict__ read_off, uint64_t n_bases, uint64_t t0,
-                                       uint32_t tile_len, uint32_t r0, uint32_t r1, uint32_t l, int lane,
-                                       uint32_t &na, uint32_t &halo_n_out) {
+template <class WL>
+__device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t *__restrict__ bases,
+                                                const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
+                                                uint64_t t0, uint32_t tile_len, uint32_t r0, uint32_t r1, uint32_t l,
+                                                int lane, uint32_t &na, uint32_t &halo_n_out, uint64_t bpos0,
+                                                uint32_t prev_byte0, bool forced0) {
     // 1. mark read starts strictly inside the tile (forced run heads: every read starts a new run,
-    //    src/nthash_hpc.rs:138-150 runs per read)
-    for (uint64_t r = (uint64_t)r0 + 1 + lane; r <= r1; r += 64) {
-        uint64_t s = read_off[r];
-        if (s > t0 && s < t0 + tile_len) {
-            uint32_t o = (uint32_t)(s - t0);
-            atomicOr(reinterpret_cast<unsigned int *>(D + (o & ~3u)), 0x80u << (8 * (o & 3u)));
+    //    src/nthash_hpc.rs:138-150 runs per read).  bpos0 = read_off[r0 + 1 + lane] was fetched ahead.
+    {
+        uint64_t sp = bpos0;
+        for (uint64_t c0 = 0;; c0 += 64) {
+            if (sp > t0 && sp < t0 + tile_len) {
+                uint32_t o = (uint32_t)(sp - t0);
+                atomicOr(reinterpret_cast<unsigned int *>(D + (o & ~3u)), 0x80u << (8 * (o & 3u)));
+            }
+            if ((uint64_t)r0 + 1 + c0 + 64 > (uint64_t)r1) break; // wave-uniform: all starts up to r1 covered
+            const uint64_t ri = (uint64_t)r0 + 1 + c0 + 64 + lane;
+            sp = ri <= n_reads ? read_off[ri] : ~0ull;
         }
     }
     wave_sync();
@@ -245,9 +353,8 @@ __device__ inline uint32_t hpc_compact(uint8_t *D, WaveLds &S, const uint8_t *__
     }
     uint32_t prevw;
     if (lane == 0) {
-        bool forced = (t0 == 0) || (read_off[r0] == t0);
-        if (forced) c[0] |= 0x80u;
-        prevw = (t0 > 0) ? ((uint32_t)bases[t0 - 1] << 24) : 0u;
+        if (forced0) c[0] |= 0x80u; // the tile starts a read
+        prevw = prev_byte0 << 24;
     } else {
         prevw = (uint32_t)D[TILE_T * lane - 1] << 24;
     }
@@ -336,7 +443,8 @@ __device__ inline uint32_t hpc_compact(uint8_t *D, WaveLds &S, const uint8_t *__
 }
 
 // tile-relative raw offset of run head x (x < R: inside the tile, else halo head x-R); false if it does not exist
-__device__ inline bool hpc_rawpos(const WaveLds &S, uint32_t x, uint32_t R, uint32_t halo_n, uint32_t &raw) {
+template <class WL>
+__device__ __forceinline__ bool hpc_rawpos(const WL &S, uint32_t x, uint32_t R, uint32_t halo_n, uint32_t &raw) {
     if (x >= R) {
         uint32_t hx = x - R;
         if (hx >= halo_n) return false;
@@ -362,211 +470,396 @@ __device__ inline bool hpc_rawpos(const WaveLds &S, uint32_t x, uint32_t R, uint
     return true;
 }
 
-template <int L, bool HPC>
-__global__ __launch_bounds__(64 * TW) void tile_minimizer_kernel(
-    const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
-    uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
-    uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts) {
-    __shared__ BlockLds B;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t l = L > 0 ? (uint32_t)L : sem.l;
-    for (int c = threadIdx.x; c < 256; c += 64 * TW) {
-        // Hpc tiles carry read-start marks in bit 7 (input is 7-bit there), so the table ignores it
-        uint32_t cc = HPC ? (c & 0x7F) : c;
-        uint32_t h = seed_h_scalar(cc), r = seed_rc_scalar(cc);
-        B.t_in[c] = make_uint2(h, rotl32(r, l - 1));
-        B.t_out[c] = make_uint2(rotl32(h, l), rotr32(r, 1));
-    }
-    __syncthreads(); // the only workgroup barrier; waves are independent from here on
-    const uint64_t t = (uint64_t)blockIdx.x * TW + w;
-    if (t >= n_tiles) return;
-    WaveLds &S = B.w[w];
-    uint8_t *D = S.buf + HS_OFF;
-    const uint64_t t0 = t * (uint64_t)TILE_BASES;
-    const uint64_t rem = n_bases - t0;
-    const uint32_t avail = rem > (uint64_t)(TILE_BASES + 128) ? (uint32_t)(TILE_BASES + 128) : (uint32_t)rem;
-    const uint32_t tile_len = rem > (uint64_t)TILE_BASES ? (uint32_t)TILE_BASES : (uint32_t)rem;
-    const uint32_t r0 = tile_read0[t], r1 = tile_read0[t + 1];
+// phase stamps for the S2K_DEBUG_SKIP&8 diagnostic path (never set in production runs): cycles per
+// phase are kept in registers and flushed once per tile to one of 64 shards
+#define S2K_STAMP(i)                                                                     \
+    do {                                                                                 \
+        if (sem.dbg_skip & 8) {                                                          \
+            uint64_t _n = __builtin_amdgcn_s_memtime();                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+            ph[i] += _n - stamp;                                                         \
+            stamp = _n;                                                                  \
+        }                                                                                \
+    } while (0)
 
-    // ---- stage the tile (+128 B look-ahead) in LDS: 1 KiB per wave-instruction, zero past the end ----
-    uint32_t na = 0;
-    {
-        const uint8_t *g = bases + t0;
-#pragma unroll
-        for (int r = 0; r < 10; r++) {
-            uint32_t off = 16 * lane + 1024 * r;
-            if (r == 9 && lane >= 8) break;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (off + 16 <= avail) {
-                v = *reinterpret_cast<const uint4 *>(g + off);
-            } else if (off < avail) {
-                uint32_t tmp[4] = {0, 0, 0, 0};
-                for (uint32_t b = 0; off + b < avail && b < 16; b++) tmp[b >> 2] |= (uint32_t)g[off + b] << (8 * (b & 3));
-                v = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
-            }
-            if (r < 9) na |= (v.x | v.y | v.z | v.w);
-            *reinterpret_cast<uint4 *>(D + off) = v;
-        }
-        if (lane == 0) S.buf[HS_OFF - 1] = 0;
-#pragma unroll
-        for (int g2 = 0; g2 < 5; g2++) S.hm[lane][g2] = 0;
-    }
-    wave_sync();
-
-    uint32_t nh = tile_len; // number of hash positions owned by this tile
-    uint32_t halo_n = 0;
-    int np = 9;
-    if (HPC) {
-        nh = hpc_compact(D, S, bases, read_off, n_bases, t0, tile_len, r0, r1, l, lane, na, halo_n);
-        if (__any((na & 0x80808080u) != 0)) { // bytes >= 0x80: the exact path is the serial kernel
-            if (lane == 0) counts->non_ascii = 1;
-        }
-        int need = (int)((nh + 1023) >> 10);
-        np = need <= 1 ? 1 : need <= 3 ? 3 : need <= 5 ? 5 : need <= 7 ? 7 : 9;
-    }
-    const uint32_t Tq = 16 * np;
-    if (nh == 0 || !sem.enabled) {
-        if (lane == 0) {
-            tile_cnt[t] = 0;
-            tile_rec_off[t] = 0;
-        }
-        return;
-    }
-
-    // ---- the hot loop ------------------------------------------------------------------------------
-    hash_stage<L>(D, B.t_in, B.t_out, sem.bound_le, lane, S, l, np);
-    wave_sync();
-
-    // ---- dense phase: bitmasks -> ordered hit list -> validated records ------------------------------
-    uint32_t cnt = 0;
+// Dense phase of one tile: hit bitmasks -> validated, ordered minimizer records.  Returns the number of
+// records (tile_cnt) and sets `base` (tile_rec_off).  See the file header for the idea.
+template <bool HPC, class WL>
+__device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const uint2 *t_in, const uint2 *t_out,
+                                                const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t t,
+                                                uint64_t t0, uint32_t tile_len, uint32_t nh, uint32_t halo_n,
+                                                uint32_t Tq, uint32_t l, uint32_t r0, uint32_t r1, uint64_t bpos0,
+                                                uint64_t rs0, int lane, const Records &rec, uint64_t *pool_cursor,
+                                                uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem, uint64_t *ph,
+                                                uint64_t &stamp) {
+    // (1) read starts that matter for this tile -> hash-space boundaries HB; an l-mer x is invalid iff
+    //     some boundary has HB - w <= x <= HB - 1  (w = l-1 raw positions for Regular: the l-mer must end
+    //     before the next read, src/lib.rs:215-230; w = l run heads for Hpc: head x+l must exist in the
+    //     same read, src/nthash_hpc.rs:265-267).  The first read start at or after the tile end (or the
+    //     end of the stream) is the one external boundary.
+    const uint32_t wclr = HPC ? l : l - 1;
+    uint32_t vm[5]; // validated hit mask of this lane
     {
         int vc = (int)nh - (int)(Tq * lane); // hash positions of this lane that exist
 #pragma unroll
         for (int d = 0; d < 5; d++) {
             int v = vc - 32 * d;
             uint32_t keep = v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
-            uint32_t word = S.hm[lane][d] & keep;
-            S.hm[lane][d] = word;
-            cnt += __popc(word);
+            vm[d] = S.hm[lane][d] & keep;
         }
     }
-    const uint32_t incl = wave_incl_scan(cnt, lane);
-    S.hoff[lane] = incl - cnt;
-    const uint32_t N = bcast(incl, 63); // raw hits in this tile
-    if (N == 0) {
-        if (lane == 0) {
-            tile_cnt[t] = 0;
-            tile_rec_off[t] = 0;
-        }
-        return;
-    }
-    uint64_t base = 0;
-    if (lane == 0) base = atomicAdd((unsigned long long *)pool_cursor, (unsigned long long)N);
-    base = ((uint64_t)bcast((uint32_t)(base >> 32), 0) << 32) | bcast((uint32_t)base, 0);
-    if (base + N > rec.capacity) { // record pool exhausted: the host re-runs with pool_needed
-        if (lane == 0) {
-            counts->pool_overflow = 1;
-            atomicMax((unsigned long long *)&counts->pool_needed, (unsigned long long)(base + N));
-            tile_cnt[t] = 0;
-            tile_rec_off[t] = 0;
-        }
-        return;
-    }
-    wave_sync();
-
-    uint32_t n_valid = 0;
-    for (uint32_t k0 = 0; k0 < N; k0 += 64) {
-        const uint32_t kk = k0 + lane;
-        const bool act = kk < N;
-        // owner lane and lane-local bit of hit kk
-        uint32_t o = 0;
+    const uint64_t tile_end = t0 + tile_len;
+    uint32_t nb = 0;                  // internal boundaries (reads r0+1 .. r0+nb start inside the tile)
+    const bool many = (r1 - r0) > 62; // more read starts than the LDS lists hold: generic per-hit lookups
+    if (lane == 0) S.rs[0] = rs0;
+    {
+        uint64_t bpos = bpos0; // read_off[r0 + 1 + lane], fetched ahead; later chunks are loaded here (rare)
+        for (uint32_t c0 = 0;; c0 += 64) { // wave-uniform; one trip unless the tile holds > 63 read starts
+            const bool internal = bpos > t0 && bpos < tile_end;
+            const bool external = bpos >= tile_end; // entry n_reads (end of stream) always qualifies
+            const uint64_t em = __ballot(external);
+            const int first_ext = em ? __builtin_ctzll(em) : 64;
+            int32_t HB = 0x7FFFFFFF;
+            if (internal || (external && lane == first_ext)) {
+                if constexpr (HPC) {
+                    if (bpos < tile_end) { // rank of the forced run head at raw offset bpos - t0
+                        const uint32_t rel = (uint32_t)(bpos - t0), o = rel / TILE_T, wi = rel % TILE_T;
+                        const uint32_t g = wi >> 5, pi = wi & 31, d = pi >> 2, bb = pi & 3;
+                        const uint32_t before = (((1u << d) - 1u) * 0x01010101u) | ((0x01010101u << d) & ((1u << (8 * bb)) - 1u));
+                        uint32_t c = S.hbase[o];
+                        for (uint32_t gg = 0; gg < g; gg++) c += __popc(S.fm[o][gg]);
+                        c += __popc(S.fm[o][g] & before);
+                        HB = (int32_t)c;
+                    } else { // first read start (or stream end) after the tile: count the run heads before it
+                        const uint64_t relb = bpos - t0;
+                        uint32_t c = 0;
+                        for (uint32_t i = 0; i < halo_n; i++) c += ((uint64_t)S.halo_pos[i] < relb);
+                        HB = (int32_t)(nh + c);
+                    }
+                } else {
+                    const uint64_t rel = bpos - t0;
+                    HB = rel > 0x3FFFFFFFull ? 0x3FFFFFFF : (int32_t)rel;
+                }
+            }
+            // every lane clears [HB - w, HB - 1] for each boundary of this chunk
+            uint64_t todo = __ballot(internal) | (em ? (1ull << first_ext) : 0ull);
+            while (todo) {
+                const int z = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int32_t hbz = (int32_t)bcast((uint32_t)HB, z);
+                const int lo = hbz - (int)wclr - (int)(Tq * lane), hi = hbz - 1 - (int)(Tq * lane); // lane-local, inclusive
+                if (hi >= 0 && lo < (int)Tq) {
 #pragma unroll
-        for (int step = 32; step; step >>= 1)
-            if (S.hoff[o + step] <= kk) o += step;
-        uint32_t bit = 0, x = 0, hv = 0;
-        bool need_re = false;
-        if (act) {
-            bit = select_nth_160(S.hm[o], kk - S.hoff[o]);
-            x = Tq * o + bit;
-            const uint32_t piece = bit >> 3;
-            const uint32_t pbyte = reinterpret_cast<const uint8_t *>(S.hm[o])[piece];
-            const uint32_t later = pbyte >> ((bit & 7) + 1);
-            // the kept hash belongs to the piece's last raw hit; pieces cut by nh may hold a stale one
-            need_re = later != 0 || (Tq * o + 8 * piece + 8 > nh);
-            hv = S.caps[piece][o];
+                    for (int d = 0; d < 5; d++) {
+                        const int a = lo - 32 * d, bnd = hi - 32 * d;
+                        if (bnd >= 0 && a < 32) {
+                            const uint32_t m_hi = bnd >= 31 ? 0xFFFFFFFFu : ((2u << bnd) - 1u);
+                            const uint32_t m_lo = a <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << a);
+                            vm[d] &= ~(m_hi & m_lo);
+                        }
+                    }
+                }
+            }
+            if (!many && internal && c0 + lane < 63) { // remembered for the per-hit read lookup
+                S.hb[c0 + lane] = HB;
+                S.rs[c0 + lane + 1] = bpos;
+            }
+            nb += (uint32_t)__popcll(__ballot(internal));
+            if (em) break;
+            const uint64_t ri = (uint64_t)r0 + 1 + c0 + 64 + lane;
+            bpos = ri <= n_reads ? read_off[ri] : ~0ull;
         }
-        // re-derive the hash of hits that were not the last of their piece, one at a time, whole wave
-        uint64_t jobs = __ballot(need_re);
-        while (jobs) {
-            const int z = __builtin_ctzll(jobs);
-            jobs &= jobs - 1;
-            const uint32_t xz = bcast(x, z);
+    }
+    S2K_STAMP(3); // boundaries
+    // (2) per-lane counts -> offsets
+    const uint32_t cnt = __popc(vm[0]) + __popc(vm[1]) + __popc(vm[2]) + __popc(vm[3]) + __popc(vm[4]);
+    const uint32_t incl = wave_incl_scan(cnt, lane);
+    const uint32_t myoff = incl - cnt;
+    const uint32_t N = bcast(incl, 63); // valid minimizers of this tile
+    base = t * rec.slab_cap;
+    if (N == 0) return 0;
+    if (N > rec.slab_cap) { // rare: more hits than the per-tile slab holds
+        uint64_t got = 0;
+        if (lane == 0) got = atomicAdd((unsigned long long *)pool_cursor, (unsigned long long)N);
+        got = ((uint64_t)bcast((uint32_t)(got >> 32), 0) << 32) | bcast((uint32_t)got, 0);
+        base = rec.ovf_base + got;
+        if (base + N > rec.capacity) { // overflow region exhausted: the host re-runs with pool_needed
+            if (lane == 0) {
+                counts->pool_overflow = 1;
+                atomicMax((unsigned long long *)&counts->pool_needed, (unsigned long long)(got + N));
+            }
+            base = 0;
+            return 0;
+        }
+    }
+    uint32_t njobs = 0;
+    auto flush_jobs = [&]() {
+        wave_sync();
+        if ((uint32_t)lane < njobs) {
+            const uint8_t *q = D + S.jobx[lane];
             uint32_t f = 0, r = 0;
-            if ((uint32_t)lane < l) { // closed form: src/nthash_hpc.rs:144,168
-                const uint32_t c = D[xz + lane];
-                f = rotl32(B.t_in[c].x, l - 1 - lane);
-                r = rotl32(rotl32(B.t_out[c].y, 1), lane);
+            for (uint32_t i = 0; i < l; i++) { // t_in[c] = {h[c], rotl(rc[c], l-1)}
+                const uint2 ti = t_in[q[i]];
+                f ^= rotl32(ti.x, l - 1 - i);
+                r ^= rotr32(ti.y, l - 1 - i);
             }
-            f = wave_xor(f);
-            r = wave_xor(r);
-            if (lane == z) hv = f < r ? f : r;
+            rec.hash[base + S.jobslot[lane]] = f < r ? f : r;
         }
-        // positions in the stream, read lookup, validation
-        uint64_t p = 0, e = 0; // l-mer start; one past the last position that must belong to the same read
-        bool ok = act;
-        if (act) {
-            if (HPC) {
-                uint32_t rp = 0, re = 0;
-                hpc_rawpos(S, x, nh, halo_n, rp);
-                ok = hpc_rawpos(S, x + l, nh, halo_n, re); // head p+l must exist (src/nthash_hpc.rs:265-267)
-                p = t0 + rp;
-                e = t0 + re + 1;
-            } else {
-                p = t0 + x;
-                e = p + l;
+        njobs = 0;
+        wave_sync();
+    };
+    // (3) batches of up to LISTCAP hits: lanes list their own hits (ascending), then every lane takes one hit.
+    //     No global LOADS in here: a load would make the compiler drain the previous round's stores.
+    for (uint32_t b0 = 0; b0 < N; b0 += LISTCAP) {
+        wave_sync();
+        {
+            uint32_t k = myoff;
+#pragma unroll
+            for (int d = 0; d < 5; d++) {
+                uint32_t wv = vm[d];
+                while (wv) {
+                    const uint32_t bit = __builtin_ctz(wv);
+                    wv &= wv - 1;
+                    if (k >= b0 && k < b0 + LISTCAP) S.list[k - b0] = (uint16_t)(Tq * lane + 32 * d + bit);
+                    k++;
+                }
             }
         }
-        uint32_t rid = r0;
-        if (act) { // last r in [r0, r1] with read_off[r] <= p
-            uint32_t lo = r0, hi = r1;
-            while (lo < hi) {
-                uint32_t mid = lo + (hi - lo + 1) / 2;
-                if (read_off[mid] <= p) lo = mid;
-                else hi = mid - 1;
+        wave_sync();
+        S2K_STAMP(4); // scan + list
+        const uint32_t bn = N - b0 < (uint32_t)LISTCAP ? N - b0 : (uint32_t)LISTCAP;
+        auto rounds = [&](auto many_c) {
+        constexpr bool MANY = decltype(many_c)::value;
+        for (uint32_t k0 = 0; k0 < bn; k0 += 64) {
+            const uint32_t kk = k0 + lane;
+            const bool act = kk < bn;
+            uint32_t x = 0, hv = 0;
+            bool need_re = false;
+            if (act) {
+                x = S.list[kk];
+                const uint32_t o = x / Tq, bit = x - o * Tq, piece = bit >> 3;
+                const uint32_t pbyte = reinterpret_cast<const uint8_t *>(S.hm[o])[piece];
+                // the kept hash belongs to the piece's last raw hit; pieces cut by nh may hold a stale one
+                need_re = (pbyte >> ((bit & 7) + 1)) != 0 || (Tq * o + 8 * piece + 8 > nh);
+                hv = S.caps[piece][o];
             }
-            rid = lo;
+            // hits that were not the last raw hit of their piece (~7 %) have no kept hash: queue them; one lane
+            // per queued hit re-derives it from the l bytes (closed form, src/nthash_hpc.rs:144,168)
+            uint64_t jobs = __ballot(need_re);
+            if (sem.dbg_skip & 8) ph[7] += (uint64_t)__popcll(jobs);
+            if (sem.dbg_skip & 64) jobs = 0;
+            if (jobs) {
+                const uint32_t nj = (uint32_t)__popcll(jobs);
+                if (njobs + nj > 64) { // wave-uniform
+                    flush_jobs();
+                }
+                if (need_re) {
+                    const uint32_t q = njobs + (uint32_t)__popcll(jobs & ((1ull << lane) - 1ull));
+                    S.jobx[q] = (uint16_t)x;
+                    S.jobslot[q] = b0 + kk;
+                }
+                njobs += nj;
+            }
+            uint32_t rid = 0;
+            if (act) {
+                uint64_t p, e1; // stream position of the l-mer start; position of the last base that belongs to it
+                if constexpr (HPC) {
+                    uint32_t rp = 0, re = 0;
+                    hpc_rawpos(S, x, nh, halo_n, rp);
+                    hpc_rawpos(S, x + l, nh, halo_n, re); // exists: the hit survived validation
+                    p = t0 + rp;
+                    e1 = t0 + re - 1; // st[p+l] - 1, src/nthash_hpc.rs:281
+                } else {
+                    p = t0 + x;
+                    e1 = p + l - 1; // src/lib.rs:226
+                }
+                uint64_t rstart;
+                if constexpr (!MANY) {
+                    uint32_t c = 0;
+                    for (uint32_t i = 0; i < nb; i++) c += (S.hb[i] <= (int32_t)x); // wave-uniform trip count, LDS broadcast
+                    rid = r0 + c;
+                    rstart = S.rs[c];
+                } else {
+                    // > 62 reads start in this tile: search the read table itself.  The volatile asm keeps these
+                    // (cold) loads from being merged into the common path's wait counters.
+                    uint32_t lo = r0, hi = r1;
+                    while (lo < hi) {
+                        uint32_t mid = lo + (hi - lo + 1) / 2;
+                        if (read_off[mid] <= p) lo = mid;
+                        else hi = mid - 1;
+                    }
+                    rid = lo;
+                    rstart = read_off[rid];
+                }
+                const uint64_t slot = base + b0 + kk;
+                if (!(sem.dbg_skip & 16)) {
+                rec.j[slot] = (uint32_t)(p - rstart);
+                rec.jend[slot] = (uint32_t)(e1 - rstart);
+                if (!need_re) rec.hash[slot] = hv;
+                rec.rid[slot] = rid;
+                }
+            }
+            // per-read minimizer counts: one atomic per (round, read)
+            uint64_t remm = __ballot(act);
+            if (sem.dbg_skip & 32) remm = 0;
+            while (remm) {
+                const int z = __builtin_ctzll(remm);
+                const uint32_t rz = bcast(rid, z);
+                const uint64_t same = __ballot(act && rid == rz);
+                if (lane == z) atomicAdd(&mn_cnt[rz], (uint32_t)__popcll(same));
+                remm &= ~same;
+            }
         }
-        uint32_t j = 0, je = 0;
-        if (act) {
-            const uint64_t rs = read_off[rid], rend = read_off[rid + 1];
-            ok = ok && e <= rend;
-            j = (uint32_t)(p - rs);
-            je = HPC ? (uint32_t)(e - 2 - rs) : j + l - 1; // src/nthash_hpc.rs:281 / src/lib.rs:226
-        }
-        const uint64_t vmask = __ballot(ok);
-        if (ok) {
-            const uint32_t rank = __popcll(vmask & ((1ull << lane) - 1ull));
-            const uint64_t slot = base + n_valid + rank;
-            rec.j[slot] = j;
-            rec.jend[slot] = je;
-            rec.hash[slot] = hv;
-            rec.rid[slot] = rid;
-        }
-        n_valid += __popcll(vmask);
-        // per-read minimizer counts: one atomic per (wave round, read)
-        uint64_t remm = vmask;
-        while (remm) {
-            const int z = __builtin_ctzll(remm);
-            const uint32_t rz = bcast(rid, z);
-            const uint64_t same = __ballot(ok && rid == rz);
-            if (lane == z) atomicAdd(&mn_cnt[rz], (uint32_t)__popcll(same));
-            remm &= ~same;
-        }
+        };
+        // > 62 reads starting in one tile take the variant that searches the read table itself; keeping it a
+        // separate instantiation keeps its global loads out of the common loop
+        if (many) rounds(std::true_type{});
+        else rounds(std::false_type{});
     }
-    if (lane == 0) {
-        tile_cnt[t] = n_valid;
-        tile_rec_off[t] = base;
+    if (njobs) flush_jobs();
+    return N;
+}
+
+// Persistent kernel: every wave walks tiles t = wave_id, wave_id + n_waves, ...  While a tile is being
+// hashed, the next tile's 9344 bytes are already in flight into registers (NPRE x 16 B per lane), and the
+// read-table entries of the current tile are fetched before they are needed, so no global-load latency
+// sits on the critical path except in the first iteration.
+template <int L, bool HPC>
+__global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
+    const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
+    uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
+    uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using WL = WaveLdsT<HPC>;
+    uint2 *t_in = reinterpret_cast<uint2 *>(smem);
+    uint2 *t_out = t_in + 256;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap(); // lut() assumes it
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t l = L > 0 ? (uint32_t)L : sem.l;
+    for (int c = threadIdx.x; c < 256; c += 64 * TW) {
+        // Hpc tiles carry read-start marks in bit 7 (input is 7-bit there), so the table ignores it
+        uint32_t cc = HPC ? (c & 0x7F) : c;
+        uint32_t h = seed_h_scalar(cc), r = seed_rc_scalar(cc);
+        t_in[c] = make_uint2(h, rotl32(r, l - 1));
+        t_out[c] = make_uint2(rotl32(h, l), rotr32(r, 1));
     }
+    __syncthreads(); // the only workgroup barrier; waves are independent from here on
+    WL &S = *reinterpret_cast<WL *>(smem + TABLE_BYTES + (size_t)w * sizeof(WL));
+    uint8_t *D = S.buf + HS_OFF;
+    const uint64_t n_waves = (uint64_t)gridDim.x * TW;
+    uint64_t t = (uint64_t)blockIdx.x * TW + w;
+    if (t >= n_tiles) return;
+    uint64_t stamp = __builtin_amdgcn_s_memtime();
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // a tile is "full" when the tile and its 128 B look-ahead lie inside the stream: staged branch-free
+    auto is_full = [&](uint64_t tt) { return (tt + 1) * (uint64_t)TILE_BASES + 128 <= n_bases; };
+    uint4 pre[NPRE];
+    uint32_t r0 = 0, r1 = 0, prevb = 0;
+    bool have_pre = false;
+    auto prefetch = [&](uint64_t tt) { // issue the loads for tile tt; nothing waits here
+        const uint8_t *g = bases + tt * (uint64_t)TILE_BASES;
+#pragma unroll
+        for (int r = 0; r < NPRE; r++) {
+            const uint32_t off = 16 * lane + 1024 * r;
+            pre[r] = (r < NPRE - 1 || lane < 8) ? *reinterpret_cast<const uint4 *>(g + off) : make_uint4(0, 0, 0, 0);
+        }
+        r0 = tile_read0[tt];
+        r1 = tile_read0[tt + 1];
+        prevb = tt > 0 ? (uint32_t)g[-1] : 0u;
+    };
+    if (is_full(t)) {
+        prefetch(t);
+        have_pre = true;
+    }
+
+    for (; t < n_tiles; t += n_waves) {
+        const uint64_t t0 = t * (uint64_t)TILE_BASES;
+        const uint64_t rem = n_bases - t0;
+        const uint32_t avail = rem > (uint64_t)(TILE_BASES + 128) ? (uint32_t)(TILE_BASES + 128) : (uint32_t)rem;
+        const uint32_t tile_len = rem > (uint64_t)TILE_BASES ? (uint32_t)TILE_BASES : (uint32_t)rem;
+        uint32_t na = 0;
+        // ---- stage the tile (+128 B look-ahead) in LDS: 1 KiB per wave-instruction ----------------------
+        if (have_pre) {
+#pragma unroll
+            for (int r = 0; r < NPRE; r++) {
+                const uint32_t off = 16 * lane + 1024 * r;
+                if (r < NPRE - 1) na |= (pre[r].x | pre[r].y | pre[r].z | pre[r].w);
+                if (r < NPRE - 1 || lane < 8) *reinterpret_cast<uint4 *>(D + off) = pre[r];
+            }
+        } else { // tile at the end of the stream: guarded loads, zero past the end
+            const uint8_t *g = bases + t0;
+            for (int r = 0; r < NPRE; r++) {
+                const uint32_t off = 16 * lane + 1024 * r;
+                if (r == NPRE - 1 && lane >= 8) break;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (off + 16 <= avail) {
+                    v = *reinterpret_cast<const uint4 *>(g + off);
+                } else if (off < avail) {
+                    uint32_t tmp[4] = {0, 0, 0, 0};
+                    for (uint32_t b = 0; off + b < avail && b < 16; b++) tmp[b >> 2] |= (uint32_t)g[off + b] << (8 * (b & 3));
+                    v = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                }
+                if (r < NPRE - 1) na |= (v.x | v.y | v.z | v.w);
+                *reinterpret_cast<uint4 *>(D + off) = v;
+            }
+            r0 = tile_read0[t];
+            r1 = tile_read0[t + 1];
+            prevb = t0 > 0 ? (uint32_t)bases[t0 - 1] : 0u;
+        }
+        const uint32_t cr0 = r0, cr1 = r1, cprev = prevb; // this tile's values (the registers get reused below)
+        // read-table entries of this tile: consumed in the dense phase, long after they arrive
+        const uint64_t bri = (uint64_t)cr0 + 1 + lane;
+        const uint64_t bpos0 = bri <= n_reads ? read_off[bri] : ~0ull;
+        const uint64_t rs0 = read_off[cr0];
+        if (lane == 0) S.buf[HS_OFF - 1] = 0;
+#pragma unroll
+        for (int g2 = 0; g2 < 5; g2++) S.hm[lane][g2] = 0;
+        wave_sync();
+        S2K_STAMP(0); // staging
+
+        uint32_t nh = tile_len; // number of hash positions owned by this tile
+        uint32_t halo_n = 0;
+        int np = 9;
+        if constexpr (HPC) {
+            if (!(sem.dbg_skip & 4))
+                nh = hpc_compact(D, S, bases, read_off, n_reads, n_bases, t0, tile_len, cr0, cr1, l, lane, na, halo_n, bpos0,
+                                 cprev, t0 == 0 || rs0 == t0);
+            if (__any((na & 0x80808080u) != 0)) { // bytes >= 0x80: the exact path is the serial kernel
+                if (lane == 0) counts->non_ascii = 1;
+            }
+            int need = (int)((nh + 1023) >> 10);
+            np = need <= 1 ? 1 : need <= 3 ? 3 : need <= 5 ? 5 : need <= 7 ? 7 : 9;
+        }
+        S2K_STAMP(1); // hpc compaction
+        // ---- next tile's loads go out now and land while this tile is hashed -----------------------------
+        have_pre = false;
+        if (t + n_waves < n_tiles && is_full(t + n_waves)) {
+            prefetch(t + n_waves);
+            have_pre = true;
+        }
+        const uint32_t Tq = 16 * np;
+        uint32_t N = 0;
+        uint64_t base = 0;
+        if (nh != 0 && sem.enabled) {
+            // ---- the hot loop ------------------------------------------------------------------------------
+            if (!(sem.dbg_skip & 1)) hash_stage<L, HPC>(D, t_in, t_out, sem.bound_le, lane, S, l, np);
+            wave_sync();
+            S2K_STAMP(2); // hash loop
+            if (!(sem.dbg_skip & 2))
+                N = dense_phase<HPC>(S, D, t_in, t_out, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
+                                     rs0, lane, rec, pool_cursor, mn_cnt, counts, base, sem, ph, stamp);
+            S2K_STAMP(5); // rounds
+        }
+        if (lane == 0) {
+            tile_cnt[t] = N;
+            tile_rec_off[t] = base;
+        }
+        wave_sync(); // LDS of this wave is reused by the next tile
+        S2K_STAMP(6); // tail
+    }
+    if ((sem.dbg_skip & 8) && lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd((unsigned long long *)&counts->dbg_cycles[blockIdx.x & 63][i], (unsigned long long)ph[i]);
 }
 
 // tile_read0[t] = last read index r (0 <= r < n_reads) with read_off[r] <= min(t*TILE, n_bases)
@@ -586,18 +879,42 @@ __global__ __launch_bounds__(256) void tile_index_kernel(const uint64_t *__restr
     tile_read0[t] = (uint32_t)lo;
 }
 
-template <int L>
-hipError_t launch_tiles_l(bool hpc, dim3 g, dim3 b, hipStream_t st, const uint8_t *bases, const uint64_t *read_off,
-                          uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles, const uint32_t *tile_read0, Sem sem,
-                          Records rec, uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt,
-                          uint32_t *mn_cnt, Counts *counts) {
-    if (hpc)
-        hipLaunchKernelGGL((tile_minimizer_kernel<L, true>), g, b, 0, st, bases, read_off, n_reads, n_bases, n_tiles,
-                           tile_read0, sem, rec, pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts);
-    else
-        hipLaunchKernelGGL((tile_minimizer_kernel<L, false>), g, b, 0, st, bases, read_off, n_reads, n_bases, n_tiles,
-                           tile_read0, sem, rec, pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts);
+template <int L, bool HPC>
+hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
+                           uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
+                           uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts) {
+    auto kern = tile_minimizer_kernel<L, HPC>;
+    const int lds = block_lds_bytes<HPC>();
+    static int n_cu = 0, per_cu = 0; // per instantiation
+    if (n_cu == 0) {
+        S2K_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        int dev = 0;
+        S2K_HIP_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        S2K_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        int occ = 0;
+        S2K_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64 * TW, lds));
+        per_cu = occ < 1 ? 1 : occ;
+        n_cu = prop.multiProcessorCount;
+    }
+    uint64_t blocks = (n_tiles + TW - 1) / TW;
+    const uint64_t resident = (uint64_t)n_cu * per_cu;
+    if (blocks > resident) blocks = resident; // persistent: waves loop over the remaining tiles
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * TW), lds, st, bases, read_off, n_reads, n_bases, n_tiles,
+                       tile_read0, sem, rec, pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts);
     return hipGetLastError();
+}
+
+template <int L>
+hipError_t launch_tiles_l(bool hpc, hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
+                          uint64_t n_bases, uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec,
+                          uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
+                          Counts *counts) {
+    if (hpc)
+        return launch_tiles_lh<L, true>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
+                                        tile_rec_off, tile_cnt, mn_cnt, counts);
+    return launch_tiles_lh<L, false>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
+                                     tile_rec_off, tile_cnt, mn_cnt, counts);
 }
 
 } // namespace
@@ -617,13 +934,12 @@ hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off
                                   Counts *counts, hipStream_t st) {
     if (n_tiles == 0 || n_reads == 0) return hipSuccess;
     if (sem.l > (uint32_t)MAX_L_TILED || sem.simd_seeds) return hipErrorInvalidValue;
-    dim3 g((unsigned)((n_tiles + TW - 1) / TW)), b(64 * TW);
     switch (sem.l) {
     case 31:
-        return launch_tiles_l<31>(sem.hpc, g, b, st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec,
+        return launch_tiles_l<31>(sem.hpc, st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec,
                                   pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts);
     default:
-        return launch_tiles_l<0>(sem.hpc, g, b, st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec,
+        return launch_tiles_l<0>(sem.hpc, st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec,
                                  pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts);
     }
 }
