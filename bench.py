@@ -136,10 +136,13 @@ def main():
     dt2, counts2, min_ms2, km_ms2, pipe_ms2 = timed(other, max(2, args.steps // 2), 1)
 
     # whole-job counts: the only collective on this path (RCCL all-reduce of a few words)
-    tot = torch.tensor([counts["n_bases"], counts["n_minimizers"], counts["n_kminmers"]], dtype=torch.int64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    tot_bases, tot_min, tot_km = (int(x) for x in tot.tolist())
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("s2k_sharding", os.path.join(ROOT, "rust-seq2kminmers_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    tot = sharding.allreduce_counts(counts, dist, dev)
+    tot_bases, tot_min, tot_km = tot["n_bases"], tot["n_minimizers"], tot["n_kminmers"]
 
     # ---- roofline of the dominant kernel (tiled minimizer kernel), per launch ---------------------
     # B = N_bases*1 + N_kminmers*17 + 16*(N_reads+1)   (each input byte once, each k-min-mer once)

@@ -1,0 +1,35 @@
+// Compiled and run by tests/test_cpp_facade.py.  Mirrors the doc example of src/lib.rs:57-68 and the KAT loop
+// of tests/main.rs:60-73: prints one line per k-min-mer so the Python side can diff against the oracle.
+#include "s2k.hpp"
+
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+int main(int argc, char **argv) {
+    if (argc < 6) {
+        std::fprintf(stderr, "usage: %s <seq-file> <l> <k> <density> <mode 0..3>\n", argv[0]);
+        return 2;
+    }
+    std::ifstream f(argv[1], std::ios::binary);
+    std::string seq((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    try {
+        s2k::Engine eng(0);
+        s2k::KminmersIterator it(eng, seq, std::stoul(argv[2]), std::stoul(argv[3]), std::stod(argv[4]),
+                                 (s2k::HashMode)std::stoi(argv[5]));
+        for (s2k::KminmerHash km : it)
+            std::printf("%llu %zu %zu %zu %d\n", (unsigned long long)km.get_hash(), km.start, km.end, km.offset, (int)km.rev);
+        // error behaviour: k == 0 panics in the reference (src/lib.rs:246), throws here
+        try {
+            s2k::KminmersIterator bad(eng, seq, 31, 0, 0.01, s2k::HashMode::Regular);
+            return 3;
+        } catch (const s2k::Error &e) {
+            if (e.status != S2K_ERR_K_RANGE) return 4;
+        }
+    } catch (const s2k::Error &e) {
+        std::fprintf(stderr, "s2k error %d: %s\n", (int)e.status, e.what());
+        return 1;
+    }
+    return 0;
+}
