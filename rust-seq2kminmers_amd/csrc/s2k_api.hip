@@ -316,7 +316,7 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
         h->path = c.serial ? 1u : 0u;
         if (c.sem.dbg_skip & 8) {
             fprintf(stderr, "[s2k dbg] phase cycles (sum over waves):");
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < 16; i++) {
                 unsigned long long sum = 0;
                 for (int sh = 0; sh < 64; sh++) sum += h->dbg_cycles[sh][i];
                 fprintf(stderr, " %llu", sum);

@@ -60,7 +60,7 @@ struct Counts { // mirrored by s2k_counts (include/s2k.h)
     // internal
     uint64_t pool_needed;
     uint32_t pool_overflow, non_ascii, km_overflow, mn_overflow;
-    uint64_t dbg_cycles[64][8]; // S2K_DEBUG_SKIP & 8: shader-clock cycles per phase, summed over waves
+    uint64_t dbg_cycles[64][16]; // S2K_DEBUG_SKIP & 8: shader-clock cycles per phase, summed over waves
 };
 
 constexpr int XOR_SHARDS = 4096;

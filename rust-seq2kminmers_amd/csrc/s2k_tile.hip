@@ -46,6 +46,7 @@ struct HpcLds {
     uint32_t fm[64][5];      // run-head flags of the lane's 144 raw bytes, 32-byte groups, bit 8b+d <-> byte 4d+b
     uint32_t hbase[64];      // exclusive prefix of per-lane run-head counts
     uint32_t halo_pos[64];   // tile-relative raw offsets of the run heads that follow the tile
+    uint8_t hl[64];          // raw lane that owns run head Tq*q (first head of hash lane q): search hint for the back-map
 };
 struct NoHpcLds {};
 
@@ -220,13 +221,23 @@ __device__ __forceinline__ void hash_loop_static(const uint8_t *D, const uint2 *
     lut_row<8, L, 0>(sin[0], W);
     lut_row<8, 0, 2048>(sout[0], W);
     uint32_t fh = 0, rh = 0;
-    {
-        uint2 wi[L];
-        lut_row<L, 0, 0>(wi, W);
+    { // warm-up: first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174), seeds fetched in two batches
+        constexpr int H1 = L < 16 ? L : 16;
+        uint2 wi[H1];
+        lut_row<H1, 0, 0>(wi, W);
 #pragma unroll
-        for (int i = 0; i < L; i++) { // warm-up: first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174)
+        for (int i = 0; i < H1; i++) {
             fh = __builtin_rotateleft32(fh, 1) ^ wi[i].x;
             rh = __builtin_rotateright32(rh, 1) ^ wi[i].y;
+        }
+        if constexpr (L > 16) {
+            uint2 wj[L - 16];
+            lut_row<L - 16, 16, 0>(wj, W);
+#pragma unroll
+            for (int i = 0; i < L - 16; i++) {
+                fh = __builtin_rotateleft32(fh, 1) ^ wj[i].x;
+                rh = __builtin_rotateright32(rh, 1) ^ wj[i].y;
+            }
         }
     }
     uint32_t cap = 0;
@@ -317,6 +328,18 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *t_in, 
     }
 }
 
+// phase stamps for the S2K_DEBUG_SKIP&8 diagnostic path (never set in production runs): cycles per
+// phase are kept in registers and flushed once per tile to one of 64 shards
+#define S2K_STAMP(i)                                                                     \
+    do {                                                                                 \
+        if (sem.dbg_skip & 8) {                                                          \
+            uint64_t _n = __builtin_amdgcn_s_memtime();                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+            ph[i] += _n - stamp;                                                         \
+            stamp = _n;                                                                  \
+        }                                                                                \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // Hpc pre-stage: in-place run-head compaction of the staged tile.  Returns R_t (run heads owned by
 // the tile) and leaves D[0..R_t) = head bytes, D[R_t..R_t+halo_n) = following heads, S.fm / S.hbase /
@@ -327,7 +350,8 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
                                                 const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
                                                 uint64_t t0, uint32_t tile_len, uint32_t r0, uint32_t r1, uint32_t l,
                                                 int lane, uint32_t &na, uint32_t &halo_n_out, uint64_t bpos0,
-                                                uint32_t prev_byte0, bool forced0) {
+                                                uint32_t prev_byte0, bool forced0, const Sem &sem, uint64_t *ph,
+                                                uint64_t &stamp) {
     // 1. mark read starts strictly inside the tile (forced run heads: every read starts a new run,
     //    src/nthash_hpc.rs:138-150 runs per read).  bpos0 = read_off[r0 + 1 + lane] was fetched ahead.
     {
@@ -343,6 +367,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         }
     }
     wave_sync();
+    S2K_STAMP(13); // compaction: read-start marks
     // 2. lane chunk -> registers
     uint32_t c[36];
     const uint4 *src = reinterpret_cast<const uint4 *>(D + TILE_T * lane);
@@ -359,6 +384,9 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         prevw = (uint32_t)D[TILE_T * lane - 1] << 24;
     }
     const uint32_t last_raw = bcast(c[35] >> 24, 63); // last raw byte of a full tile
+    // the 128 staged look-ahead bytes serve the first round of the run-head search after the tile; read them
+    // before the buffer is compacted in place (lanes 0..31, 4 bytes each)
+    const uint32_t la_word = lane < 32 ? *reinterpret_cast<const uint32_t *>(D + TILE_BASES + 4 * lane) : 0u;
     const int vb = (int)tile_len - TILE_T * lane;      // valid bytes in this lane's chunk (may be <=0 or >=144)
     const bool partial = tile_len < (uint32_t)TILE_BASES;
     // 3. pass 1: SWAR head flags -> transposed group masks + count
@@ -386,32 +414,50 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     S.hbase[lane] = base;
     // all lanes hold their raw chunk in registers now -> the buffer may be overwritten in place
     wave_sync();
+    S2K_STAMP(14); // compaction: chunk load + flags + scan
     // 4. pass 2: every byte is stored at slot (#heads at or before it) - 1; bytes of one run carry the
     //    same value, so only the slot matters.  Slot -1 of lane 0 lands on the scratch byte D[-1].
-    uint32_t gbase = base - 1;
+    {
+        typedef __attribute__((address_space(3))) uint8_t lds_u8;
+        // LDS byte address of slot 0 minus one (so that "count of heads at or before" indexes directly)
+        uint32_t gaddr = (uint32_t)(uintptr_t)(lds_u8 *)D + base - 1;
+        auto pass2 = [&](auto partial_c) {
+            constexpr bool PARTIAL = decltype(partial_c)::value;
 #pragma unroll
-    for (int d = 0; d < 36; d++) {
-        const int g = d >> 3, dd = d & 7;
+            for (int d = 0; d < 36; d++) {
+                const int g = d >> 3, dd = d & 7;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            uint32_t slot = gbase + __popc(fmk[g] & at_or_before(dd, b));
-            if (!partial || 4 * d + b < vb) D[(int)slot] = (uint8_t)(c[d] >> (8 * b));
-        }
-        if (dd == 7) gbase += __popc(fmk[g]);
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t a = gaddr + __popc(fmk[g] & at_or_before(dd, b)); // v_and + v_bcnt(+gaddr)
+                    if (!PARTIAL || 4 * d + b < vb) *reinterpret_cast<lds_u8 *>(a) = (uint8_t)(c[d] >> (8 * b));
+                }
+                if (dd == 7) gaddr += __popc(fmk[g]);
+            }
+        };
+        // full tiles (all but the last of the stream) take the branch-free instantiation
+        if (partial) pass2(std::true_type{});
+        else pass2(std::false_type{});
     }
+    S2K_STAMP(15); // compaction: byte stores
     // 5. run heads that follow the tile: up to l of them (hash needs l-1, the end position one more)
     uint32_t halo_n = 0;
     if (!partial) {
         uint64_t q = t0 + TILE_BASES;
         uint32_t pb = last_raw;
+        bool first = true;
         while (halo_n < l && q < n_bases) { // wave-uniform
+            const uint32_t span = first ? 128u : 256u; // bytes examined this round
             uint64_t a = q + 4 * (uint64_t)lane;
-            int nval = a >= n_bases ? 0 : (n_bases - a >= 4 ? 4 : (int)(n_bases - a));
+            int nval = (a >= n_bases || 4u * (uint32_t)lane >= span) ? 0 : (n_bases - a >= 4 ? 4 : (int)(n_bases - a));
             uint32_t wv = 0;
-            if (nval == 4) wv = *reinterpret_cast<const uint32_t *>(bases + a);
-            else
-                for (int b = 0; b < nval; b++) wv |= (uint32_t)bases[a + b] << (8 * b);
-            na |= wv & 0x80808080u;
+            if (first) {
+                wv = la_word; // bytes past the end of the stream were staged as zeros and are masked by nval
+            } else {
+                if (nval == 4) wv = *reinterpret_cast<const uint32_t *>(bases + a);
+                else
+                    for (int b = 0; b < nval; b++) wv |= (uint32_t)bases[a + b] << (8 * b);
+            }
+            na |= wv & (nval >= 4 ? 0x80808080u : (nval <= 0 ? 0u : (0x80808080u & ((1u << (8 * nval)) - 1u))));
             uint32_t pw = __shfl_up(wv, 1);
             if (lane == 0) pw = pb << 24;
             uint32_t prv = (wv << 8) | (pw >> 24);
@@ -432,8 +478,9 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
                 }
             }
             halo_n += bcast(in2, 63);
-            pb = bcast(wv >> 24, 63);
-            q += 256;
+            pb = bcast(wv >> 24, first ? 31 : 63);
+            q += span;
+            first = false;
         }
         if (halo_n > l) halo_n = l;
     }
@@ -442,49 +489,60 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     return R;
 }
 
-// tile-relative raw offset of run head x (x < R: inside the tile, else halo head x-R); false if it does not exist
+// Back-map of one Hpc hit: tile-relative raw offsets of run heads x and x + l (x < R; x + l may be one of the
+// run heads that follow the tile).  The owner raw lane of a head is the last o with hbase[o] <= head; S.hl
+// brackets it to the raw lanes spanned by the head's hash lane.  Written so that the LDS reads of the two
+// look-ups are independent and can be in flight together (a chain of ~10 dependent reads per look-up cost
+// ~3.4k cycles per round of 64 hits).
 template <class WL>
-__device__ __forceinline__ bool hpc_rawpos(const WL &S, uint32_t x, uint32_t R, uint32_t halo_n, uint32_t &raw) {
-    if (x >= R) {
-        uint32_t hx = x - R;
-        if (hx >= halo_n) return false;
-        raw = S.halo_pos[hx];
-        return true;
+__device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l, uint32_t R, uint32_t halo_n,
+                                            uint32_t Tq, uint32_t &raw_x, uint32_t &raw_e) {
+    const uint32_t y = x + l;
+    const bool y_in = y < R;
+    const uint32_t yy = y_in ? y : x; // look-up 2 degenerates to look-up 1 when x + l lies after the tile
+    const uint32_t q1 = x / Tq, q2 = yy / Tq;
+    uint32_t lo1 = S.hl[q1], hi1 = q1 < 63 ? S.hl[q1 + 1] : 63u;
+    uint32_t lo2 = S.hl[q2], hi2 = q2 < 63 ? S.hl[q2 + 1] : 63u;
+    // three candidates beyond lo at once; a wider bracket (long homopolymers: raw lanes without heads) loops
+    {
+        const uint32_t a1 = S.hbase[lo1 + 1 > 63 ? 63 : lo1 + 1], a2 = S.hbase[lo1 + 2 > 63 ? 63 : lo1 + 2], a3 = S.hbase[lo1 + 3 > 63 ? 63 : lo1 + 3];
+        const uint32_t b1 = S.hbase[lo2 + 1 > 63 ? 63 : lo2 + 1], b2 = S.hbase[lo2 + 2 > 63 ? 63 : lo2 + 2], b3 = S.hbase[lo2 + 3 > 63 ? 63 : lo2 + 3];
+        uint32_t o1 = lo1 + (uint32_t)(lo1 + 1 <= hi1 && a1 <= x) + (uint32_t)(lo1 + 2 <= hi1 && a2 <= x) + (uint32_t)(lo1 + 3 <= hi1 && a3 <= x);
+        uint32_t o2 = lo2 + (uint32_t)(lo2 + 1 <= hi2 && b1 <= yy) + (uint32_t)(lo2 + 2 <= hi2 && b2 <= yy) + (uint32_t)(lo2 + 3 <= hi2 && b3 <= yy);
+        while (o1 == lo1 + 3 && o1 < hi1 && S.hbase[o1 + 1] <= x) o1++, lo1++;
+        while (o2 == lo2 + 3 && o2 < hi2 && S.hbase[o2 + 1] <= yy) o2++, lo2++;
+        lo1 = o1;
+        lo2 = o2;
     }
-    uint32_t o = 0;
+    const uint32_t n1 = x - S.hbase[lo1], n2 = yy - S.hbase[lo2];
+    uint32_t w1[5], w2[5];
 #pragma unroll
-    for (int step = 32; step; step >>= 1)
-        if (S.hbase[o + step] <= x) o += step;
-    uint32_t n = x - S.hbase[o];
-    uint32_t g = 0, word = S.fm[o][0];
+    for (int d = 0; d < 5; d++) {
+        w1[d] = S.fm[lo1][d];
+        w2[d] = S.fm[lo2][d];
+    }
+    auto decode = [](const uint32_t (&w)[5], uint32_t n) {
+        uint32_t g = 0, word = w[0];
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-        uint32_t c = __popc(word);
-        if (n >= c && g == (uint32_t)d) {
-            n -= c;
-            g++;
-            word = S.fm[o][d + 1];
+        for (int d = 0; d < 4; d++) {
+            const uint32_t c = __popc(word);
+            if (n >= c && g == (uint32_t)d) {
+                n -= c;
+                g++;
+                word = w[d + 1];
+            }
         }
-    }
-    raw = TILE_T * o + 32 * g + select_nth_32(untranspose(word), n);
-    return true;
+        return 32 * g + select_nth_32(untranspose(word), n);
+    };
+    raw_x = TILE_T * lo1 + decode(w1, n1);
+    const uint32_t hx = y - R; // only meaningful when !y_in; validated hits guarantee hx < halo_n
+    const uint32_t he = S.halo_pos[(!y_in && hx < halo_n) ? hx : 0];
+    raw_e = y_in ? TILE_T * lo2 + decode(w2, n2) : he;
 }
-
-// phase stamps for the S2K_DEBUG_SKIP&8 diagnostic path (never set in production runs): cycles per
-// phase are kept in registers and flushed once per tile to one of 64 shards
-#define S2K_STAMP(i)                                                                     \
-    do {                                                                                 \
-        if (sem.dbg_skip & 8) {                                                          \
-            uint64_t _n = __builtin_amdgcn_s_memtime();                                  \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
-            ph[i] += _n - stamp;                                                         \
-            stamp = _n;                                                                  \
-        }                                                                                \
-    } while (0)
 
 // Dense phase of one tile: hit bitmasks -> validated, ordered minimizer records.  Returns the number of
 // records (tile_cnt) and sets `base` (tile_rec_off).  See the file header for the idea.
-template <bool HPC, class WL>
+template <int L, bool HPC, class WL>
 __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const uint2 *t_in, const uint2 *t_out,
                                                 const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t t,
                                                 uint64_t t0, uint32_t tile_len, uint32_t nh, uint32_t halo_n,
@@ -498,6 +556,18 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
     //     same read, src/nthash_hpc.rs:265-267).  The first read start at or after the tile end (or the
     //     end of the stream) is the one external boundary.
     const uint32_t wclr = HPC ? l : l - 1;
+    if constexpr (HPC) { // hint table for the back-map: owner raw lane of the first run head of every hash lane
+        const uint32_t xq = Tq * (uint32_t)lane;
+        uint32_t o = 0;
+        if (xq < nh) {
+#pragma unroll
+            for (int step = 32; step; step >>= 1)
+                if (S.hbase[o + step] <= xq) o += step;
+        } else {
+            o = 63;
+        }
+        S.hl[lane] = (uint8_t)o;
+    }
     uint32_t vm[5]; // validated hit mask of this lane
     {
         int vc = (int)nh - (int)(Tq * lane); // hash positions of this lane that exist
@@ -531,14 +601,22 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                         c += __popc(S.fm[o][g] & before);
                         HB = (int32_t)c;
                     } else { // first read start (or stream end) after the tile: count the run heads before it
-                        const uint64_t relb = bpos - t0;
-                        uint32_t c = 0;
-                        for (uint32_t i = 0; i < halo_n; i++) c += ((uint64_t)S.halo_pos[i] < relb);
-                        HB = (int32_t)(nh + c);
+                        HB = -1; // resolved below by the whole wave
                     }
                 } else {
                     const uint64_t rel = bpos - t0;
                     HB = rel > 0x3FFFFFFFull ? 0x3FFFFFFF : (int32_t)rel;
+                }
+            }
+            if constexpr (HPC) {
+                if (em) { // first read start (or stream end) at/after the tile end: run heads before it, counted by all lanes
+                    const uint64_t eb = ((uint64_t)bcast((uint32_t)(bpos >> 32), first_ext) << 32) | bcast((uint32_t)bpos, first_ext);
+                    if (eb >= tile_end) {
+                        const uint64_t relb = eb - t0;
+                        const bool before = (uint32_t)lane < halo_n && (uint64_t)S.halo_pos[lane] < relb;
+                        const int32_t hbx = (int32_t)(nh + (uint32_t)__popcll(__ballot(before)));
+                        if (lane == first_ext) HB = hbx;
+                    }
                 }
             }
             // every lane clears [HB - w, HB - 1] for each boundary of this chunk
@@ -592,16 +670,51 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
             return 0;
         }
     }
+    // per-read minimizer counts, once per tile: read r0+i owns the hits in [HB[i-1], HB[i])
+    if (!many) {
+        uint32_t below_prev = 0, mine = 0;
+        for (uint32_t i = 0; i <= nb; i++) { // wave-uniform trip count
+            uint32_t below = N;
+            if (i < nb) {
+                const int lim = S.hb[i] - (int)(Tq * lane); // lane-local bits [0, lim) lie below boundary i
+                uint32_t c = 0;
+#pragma unroll
+                for (int d = 0; d < 5; d++) {
+                    const int v = lim - 32 * d;
+                    const uint32_t keep = v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
+                    c += __popc(vm[d] & keep);
+                }
+                below = bcast(wave_incl_scan(c, lane), 63);
+            }
+            if ((uint32_t)lane == i) mine = below - below_prev;
+            below_prev = below;
+        }
+        if ((uint32_t)lane <= nb && mine) atomicAdd(&mn_cnt[r0 + lane], mine);
+    }
     uint32_t njobs = 0;
     auto flush_jobs = [&]() {
         wave_sync();
         if ((uint32_t)lane < njobs) {
             const uint8_t *q = D + S.jobx[lane];
             uint32_t f = 0, r = 0;
-            for (uint32_t i = 0; i < l; i++) { // t_in[c] = {h[c], rotl(rc[c], l-1)}
-                const uint2 ti = t_in[q[i]];
-                f ^= rotl32(ti.x, l - 1 - i);
-                r ^= rotr32(ti.y, l - 1 - i);
+            if constexpr (L > 0) { // all byte reads first, then all seed reads: two LDS round trips in total
+                uint32_t by[L];
+#pragma unroll
+                for (int i = 0; i < L; i++) by[i] = q[i];
+                uint2 ti[L];
+#pragma unroll
+                for (int i = 0; i < L; i++) ti[i] = t_in[by[i]]; // t_in[c] = {h[c], rotl(rc[c], l-1)}
+#pragma unroll
+                for (int i = 0; i < L; i++) {
+                    f ^= rotl32(ti[i].x, L - 1 - i);
+                    r ^= rotr32(ti[i].y, L - 1 - i);
+                }
+            } else {
+                for (uint32_t i = 0; i < l; i++) {
+                    const uint2 ti = t_in[q[i]];
+                    f ^= rotl32(ti.x, l - 1 - i);
+                    r ^= rotr32(ti.y, l - 1 - i);
+                }
             }
             rec.hash[base + S.jobslot[lane]] = f < r ? f : r;
         }
@@ -660,19 +773,20 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 }
                 njobs += nj;
             }
+            S2K_STAMP(8); // round: list read, kept hash, job queueing
             uint32_t rid = 0;
             if (act) {
                 uint64_t p, e1; // stream position of the l-mer start; position of the last base that belongs to it
                 if constexpr (HPC) {
                     uint32_t rp = 0, re = 0;
-                    hpc_rawpos(S, x, nh, halo_n, rp);
-                    hpc_rawpos(S, x + l, nh, halo_n, re); // exists: the hit survived validation
+                    hpc_rawpos2(S, x, l, nh, halo_n, Tq, rp, re); // head x + l exists: the hit survived validation
                     p = t0 + rp;
                     e1 = t0 + re - 1; // st[p+l] - 1, src/nthash_hpc.rs:281
                 } else {
                     p = t0 + x;
                     e1 = p + l - 1; // src/lib.rs:226
                 }
+                S2K_STAMP(9); // round: back-map
                 uint64_t rstart;
                 if constexpr (!MANY) {
                     uint32_t c = 0;
@@ -699,8 +813,9 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 rec.rid[slot] = rid;
                 }
             }
+            S2K_STAMP(10); // round: read lookup + stores
             // per-read minimizer counts: one atomic per (round, read)
-            uint64_t remm = __ballot(act);
+            uint64_t remm = MANY ? __ballot(act) : 0ull; // the common case counted per tile above
             if (sem.dbg_skip & 32) remm = 0;
             while (remm) {
                 const int z = __builtin_ctzll(remm);
@@ -709,6 +824,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 if (lane == z) atomicAdd(&mn_cnt[rz], (uint32_t)__popcll(same));
                 remm &= ~same;
             }
+            S2K_STAMP(11); // round: per-read counts
         }
         };
         // > 62 reads starting in one tile take the variant that searches the read table itself; keeping it a
@@ -717,6 +833,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
         else rounds(std::false_type{});
     }
     if (njobs) flush_jobs();
+    S2K_STAMP(12); // hash re-derivation
     return N;
 }
 
@@ -750,12 +867,18 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
     uint64_t t = (uint64_t)blockIdx.x * TW + w;
     if (t >= n_tiles) return;
     uint64_t stamp = __builtin_amdgcn_s_memtime();
-    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // a tile is "full" when the tile and its 128 B look-ahead lie inside the stream: staged branch-free
     auto is_full = [&](uint64_t tt) { return (tt + 1) * (uint64_t)TILE_BASES + 128 <= n_bases; };
+    // Software pipeline over this wave's tiles (cur = t, nxt = t + n_waves, nn = t + 2 n_waves):
+    //   pre[], prevb      : bases of nxt, issued while cur is hashed
+    //   r0n, r1n          : tile_read0 of nxt   (issued one iteration earlier, so their values are usable ...)
+    //   bposn, rs0n       : read_off[r0n + 1 + lane], read_off[r0n]   (... to address these, issued with pre[])
+    //   r0nn, r1nn        : tile_read0 of nn
+    // so no dependent global load is waited for on the spot after the prologue.
     uint4 pre[NPRE];
-    uint32_t r0 = 0, r1 = 0, prevb = 0;
+    uint32_t prevb = 0;
     bool have_pre = false;
     auto prefetch = [&](uint64_t tt) { // issue the loads for tile tt; nothing waits here
         const uint8_t *g = bases + tt * (uint64_t)TILE_BASES;
@@ -764,13 +887,24 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
             const uint32_t off = 16 * lane + 1024 * r;
             pre[r] = (r < NPRE - 1 || lane < 8) ? *reinterpret_cast<const uint4 *>(g + off) : make_uint4(0, 0, 0, 0);
         }
-        r0 = tile_read0[tt];
-        r1 = tile_read0[tt + 1];
         prevb = tt > 0 ? (uint32_t)g[-1] : 0u;
     };
+    auto read_entries = [&](uint32_t rr0, uint64_t &bp, uint64_t &rs) {
+        const uint64_t bri = (uint64_t)rr0 + 1 + lane;
+        bp = bri <= n_reads ? read_off[bri] : ~0ull; // entry n_reads is the end of the stream
+        rs = read_off[rr0];
+    };
+    uint32_t r0 = tile_read0[t], r1 = tile_read0[t + 1];
+    uint64_t bpos0, rs0;
+    read_entries(r0, bpos0, rs0);
     if (is_full(t)) {
         prefetch(t);
         have_pre = true;
+    }
+    uint32_t r0n = 0, r1n = 0;
+    if (t + n_waves < n_tiles) {
+        r0n = tile_read0[t + n_waves];
+        r1n = tile_read0[t + n_waves + 1];
     }
 
     for (; t < n_tiles; t += n_waves) {
@@ -803,15 +937,9 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
                 if (r < NPRE - 1) na |= (v.x | v.y | v.z | v.w);
                 *reinterpret_cast<uint4 *>(D + off) = v;
             }
-            r0 = tile_read0[t];
-            r1 = tile_read0[t + 1];
             prevb = t0 > 0 ? (uint32_t)bases[t0 - 1] : 0u;
         }
         const uint32_t cr0 = r0, cr1 = r1, cprev = prevb; // this tile's values (the registers get reused below)
-        // read-table entries of this tile: consumed in the dense phase, long after they arrive
-        const uint64_t bri = (uint64_t)cr0 + 1 + lane;
-        const uint64_t bpos0 = bri <= n_reads ? read_off[bri] : ~0ull;
-        const uint64_t rs0 = read_off[cr0];
         if (lane == 0) S.buf[HS_OFF - 1] = 0;
 #pragma unroll
         for (int g2 = 0; g2 < 5; g2++) S.hm[lane][g2] = 0;
@@ -824,7 +952,7 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
         if constexpr (HPC) {
             if (!(sem.dbg_skip & 4))
                 nh = hpc_compact(D, S, bases, read_off, n_reads, n_bases, t0, tile_len, cr0, cr1, l, lane, na, halo_n, bpos0,
-                                 cprev, t0 == 0 || rs0 == t0);
+                                 cprev, t0 == 0 || rs0 == t0, sem, ph, stamp);
             if (__any((na & 0x80808080u) != 0)) { // bytes >= 0x80: the exact path is the serial kernel
                 if (lane == 0) counts->non_ascii = 1;
             }
@@ -834,9 +962,18 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
         S2K_STAMP(1); // hpc compaction
         // ---- next tile's loads go out now and land while this tile is hashed -----------------------------
         have_pre = false;
-        if (t + n_waves < n_tiles && is_full(t + n_waves)) {
-            prefetch(t + n_waves);
-            have_pre = true;
+        uint64_t bposn = ~0ull, rs0n = 0;
+        uint32_t r0nn = 0, r1nn = 0;
+        if (t + n_waves < n_tiles) {
+            if (is_full(t + n_waves)) {
+                prefetch(t + n_waves);
+                have_pre = true;
+            }
+            read_entries(r0n, bposn, rs0n);
+            if (t + 2 * n_waves < n_tiles) {
+                r0nn = tile_read0[t + 2 * n_waves];
+                r1nn = tile_read0[t + 2 * n_waves + 1];
+            }
         }
         const uint32_t Tq = 16 * np;
         uint32_t N = 0;
@@ -847,7 +984,7 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
             wave_sync();
             S2K_STAMP(2); // hash loop
             if (!(sem.dbg_skip & 2))
-                N = dense_phase<HPC>(S, D, t_in, t_out, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
+                N = dense_phase<L, HPC>(S, D, t_in, t_out, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
                                      rs0, lane, rec, pool_cursor, mn_cnt, counts, base, sem, ph, stamp);
             S2K_STAMP(5); // rounds
         }
@@ -856,10 +993,11 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
             tile_rec_off[t] = base;
         }
         wave_sync(); // LDS of this wave is reused by the next tile
+        r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; // rotate the pipeline
         S2K_STAMP(6); // tail
     }
     if ((sem.dbg_skip & 8) && lane == 0)
-        for (int i = 0; i < 8; i++) atomicAdd((unsigned long long *)&counts->dbg_cycles[blockIdx.x & 63][i], (unsigned long long)ph[i]);
+        for (int i = 0; i < 16; i++) atomicAdd((unsigned long long *)&counts->dbg_cycles[blockIdx.x & 63][i], (unsigned long long)ph[i]);
 }
 
 // tile_read0[t] = last read index r (0 <= r < n_reads) with read_off[r] <= min(t*TILE, n_bases)
