@@ -138,6 +138,169 @@ __global__ __launch_bounds__(64 * KM_WAVES) void kminmer_kernel(
     if (lane == 0 && xacc) atomicXor((unsigned long long *)&xor_shards[t & (XOR_SHARDS - 1)], (unsigned long long)xacc);
 }
 
+
+// ---- fast path (k <= 65): 256 records per pass, three global round trips per tile -------------------------------
+// The generic kernel above pays a dependent chain of global loads per round of 64 records (records -> read table
+// -> following tiles).  Here a wave first fetches the meta data of its tile AND of the four tiles that follow
+// (where the k-1 records after the tile's last one almost always live), then all records of the pass plus those
+// k-1 "tail" records, then the per-read offsets; everything else runs out of registers and LDS.
+constexpr int KF_WAVES = 4;
+constexpr int KF_PASS = 256; // records per pass = 4 per lane
+constexpr int KF_TAIL = 64;  // k - 1 <= 64
+
+__global__ __launch_bounds__(64 * KF_WAVES) void kminmer_kernel_fast(
+    uint64_t n_tiles, const uint64_t *__restrict__ tile_rec_off, const uint32_t *__restrict__ tile_cnt,
+    const uint64_t *__restrict__ tile_goff, Records rec, const uint64_t *__restrict__ mn_off,
+    const uint64_t *__restrict__ km_off, uint32_t k, uint64_t km_capacity, uint64_t *__restrict__ o_hash,
+    uint32_t *__restrict__ o_start, uint32_t *__restrict__ o_end, uint8_t *__restrict__ o_rev, uint64_t mn_capacity,
+    uint32_t *__restrict__ o_mn_j, uint32_t *__restrict__ o_mn_jend, uint32_t *__restrict__ o_mn_hash,
+    uint64_t *__restrict__ xor_shards, const Counts *__restrict__ counts) {
+    __shared__ uint64_t s_x[KF_WAVES][KF_PASS + KF_TAIL];
+    __shared__ uint32_t s_je[KF_WAVES][KF_PASS + KF_TAIL];
+    __shared__ uint64_t s_tx[KF_WAVES][KF_TAIL];
+    __shared__ uint32_t s_tje[KF_WAVES][KF_TAIL];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t t = (uint64_t)blockIdx.x * KF_WAVES + w;
+    if (t >= n_tiles) return;
+    // round trip 1: meta data of tiles t .. t+4
+    uint32_t mc = 0;
+    uint64_t mo = 0;
+    if (lane < 5 && t + lane < n_tiles) {
+        mc = tile_cnt[t + lane];
+        mo = tile_rec_off[t + lane];
+    }
+    const uint64_t g0 = tile_goff[t];
+    const uint32_t pool_bad = counts->pool_overflow;
+    const uint32_t cnt = __shfl(mc, 0);
+    if (cnt == 0 || pool_bad) return;
+    const uint64_t roff = ((uint64_t)__shfl((uint32_t)(mo >> 32), 0) << 32) | __shfl((uint32_t)mo, 0);
+    const uint32_t K1 = k - 1;
+    // where do the K1 records after this tile's last one live?  prefix over tiles t+1 .. t+4
+    uint32_t c1 = __shfl(mc, 1), c2 = __shfl(mc, 2), c3 = __shfl(mc, 3), c4 = __shfl(mc, 4);
+    const uint32_t p1 = c1, p2 = p1 + c2, p3 = p2 + c3, p4 = p3 + c4;
+    uint64_t on[5]; // record offsets of tiles t+1 .. t+4 (shuffles stay outside divergent code)
+#pragma unroll
+    for (int jt = 1; jt <= 4; jt++) on[jt] = ((uint64_t)__shfl((uint32_t)(mo >> 32), jt) << 32) | __shfl((uint32_t)mo, jt);
+    uint64_t tx = 0;
+    uint32_t tje = 0;
+    if ((uint32_t)lane < K1) {
+        const uint32_t e = lane;
+        uint64_t a = ~0ull;
+        if (e < p4) {
+            const int jt = e < p1 ? 1 : e < p2 ? 2 : e < p3 ? 3 : 4;
+            const uint32_t before = jt == 1 ? 0 : jt == 2 ? p1 : jt == 3 ? p2 : p3;
+            const uint64_t o2 = jt == 1 ? on[1] : jt == 2 ? on[2] : jt == 3 ? on[3] : on[4];
+            a = o2 + (e - before);
+        } else { // sparse stretch: walk further (rare)
+            Cursor c{t + 5, (uint64_t)(e - p4)};
+            if (t + 5 < n_tiles && normalize(c, tile_cnt, n_tiles)) a = tile_rec_off[c.tile] + c.idx;
+        }
+        if (a != ~0ull) { // round trip 2 (together with the records below)
+            tx = mix32(rec.hash[a]);
+            tje = rec.jend[a];
+        }
+    }
+    uint64_t xacc = 0;
+    for (uint32_t base = 0; base < cnt; base += KF_PASS) {
+        uint32_t j[4], je[4], hv[4], rid[4];
+        bool have[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { // round trip 2: up to 256 records
+            const uint32_t i = base + 64 * u + lane;
+            have[u] = i < cnt;
+            j[u] = je[u] = hv[u] = rid[u] = 0;
+            if (have[u]) {
+                j[u] = rec.j[roff + i];
+                je[u] = rec.jend[roff + i];
+                hv[u] = rec.hash[roff + i];
+                rid[u] = rec.rid[roff + i];
+            }
+        }
+        uint64_t m0[4], m1[4], ko[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { // round trip 3: per-read offsets (same address for most lanes)
+            m0[u] = m1[u] = ko[u] = 0;
+            if (have[u]) {
+                m0[u] = mn_off[rid[u]];
+                m1[u] = mn_off[rid[u] + 1];
+                ko[u] = km_off[rid[u]];
+            }
+        }
+        wave_sync();
+        if (base == 0) {
+            s_tx[w][lane] = tx;
+            s_tje[w][lane] = tje;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            s_x[w][64 * u + lane] = mix32(hv[u]);
+            s_je[w][64 * u + lane] = je[u];
+        }
+        wave_sync();
+        // entries past this pass's 256: the next records of the tile (next pass) or the tail
+        {
+            const uint32_t e = KF_PASS + lane, i = base + e;
+            uint64_t x = 0;
+            uint32_t jj = 0;
+            if ((uint32_t)lane < K1) {
+                if (i < cnt) {
+                    x = mix32(rec.hash[roff + i]);
+                    jj = rec.jend[roff + i];
+                } else if (i - cnt < K1) {
+                    x = s_tx[w][i - cnt];
+                    jj = s_tje[w][i - cnt];
+                }
+            }
+            s_x[w][e] = x;
+            s_je[w][e] = jj;
+        }
+        // entries inside the 256 but past the tile's last record: tail
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = base + 64 * u + lane;
+            if (!have[u] && i - cnt < K1) {
+                s_x[w][64 * u + lane] = s_tx[w][i - cnt];
+                s_je[w][64 * u + lane] = s_tje[w][i - cnt];
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!have[u]) continue;
+            const uint32_t i = base + 64 * u + lane;
+            const uint64_t g = g0 + i;
+            const uint64_t c = g - m0[u]; // rank of this minimizer inside its read
+            const uint64_t M = m1[u] - m0[u];
+            if (o_mn_j && g < mn_capacity) {
+                o_mn_j[g] = j[u];
+                o_mn_jend[g] = je[u];
+                o_mn_hash[g] = hv[u];
+            }
+            if (c + k <= M) { // window c..c+k-1 lies inside the read: item `c` exists (lib.rs:235)
+                uint64_t F = 0, Rv = 0;
+                const int e0 = 64 * u + lane;
+                for (uint32_t m = 0; m < k; m++) {
+                    const uint64_t x = s_x[w][e0 + m];
+                    F ^= rotl64(x, k - 1 - m);
+                    Rv ^= rotl64(x, m);
+                }
+                const uint32_t end = s_je[w][e0 + k - 1];
+                const uint64_t o = ko[u] + c;
+                const uint64_t hmin = F < Rv ? F : Rv;
+                xacc ^= hmin;
+                if (o < km_capacity) {
+                    if (o_hash) o_hash[o] = hmin;
+                    if (o_start) o_start[o] = j[u];
+                    if (o_end) o_end[o] = end;
+                    if (o_rev) o_rev[o] = (uint8_t)(Rv < F);
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) xacc ^= __shfl_down(xacc, o);
+    if (lane == 0 && xacc) atomicXor((unsigned long long *)&xor_shards[t & (XOR_SHARDS - 1)], (unsigned long long)xacc);
+}
+
 } // namespace
 
 hipError_t launch_kminmers(uint64_t n_tiles, const uint64_t *tile_rec_off, const uint32_t *tile_cnt,
@@ -146,6 +309,12 @@ hipError_t launch_kminmers(uint64_t n_tiles, const uint64_t *tile_rec_off, const
                            uint8_t *o_rev, uint64_t mn_capacity, uint32_t *o_mn_j, uint32_t *o_mn_jend,
                            uint32_t *o_mn_hash, uint64_t *xor_shards, const Counts *counts, hipStream_t st) {
     if (n_tiles == 0) return hipSuccess;
+    if (k <= (uint32_t)KF_TAIL + 1) {
+        dim3 g((unsigned)((n_tiles + KF_WAVES - 1) / KF_WAVES)), b(64 * KF_WAVES);
+        hipLaunchKernelGGL(kminmer_kernel_fast, g, b, 0, st, n_tiles, tile_rec_off, tile_cnt, tile_goff, rec, mn_off, km_off, k,
+                           km_capacity, o_hash, o_start, o_end, o_rev, mn_capacity, o_mn_j, o_mn_jend, o_mn_hash, xor_shards, counts);
+        return hipGetLastError();
+    }
     dim3 g((unsigned)((n_tiles + KM_WAVES - 1) / KM_WAVES)), b(64 * KM_WAVES);
     hipLaunchKernelGGL(kminmer_kernel, g, b, 0, st, n_tiles, tile_rec_off, tile_cnt, tile_goff, rec, mn_off, km_off, k,
                        km_capacity, o_hash, o_start, o_end, o_rev, mn_capacity, o_mn_j, o_mn_jend, o_mn_hash, xor_shards, counts);
