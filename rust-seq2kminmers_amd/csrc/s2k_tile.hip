@@ -61,7 +61,7 @@ struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
     int32_t hb[64];          // read starts inside the tile, as hash-space positions (ascending)
     uint64_t rs[64];         // rs[i] = read_off[r0 + i]
 };
-constexpr int TABLE_BYTES = 2 * 256 * 8; // t_in: {h[c], rotl(rc[c], l-1)}   t_out: {rotl(h[c], l), rotr(rc[c], 1)}
+constexpr int TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c], l-1)};  OUT table at 2048: {rotl(h[c], l), rotr(rc[c], 1)}
 template <bool HPC>
 constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>); }
 static_assert(2 * block_lds_bytes<true>() <= 160 * 1024, "two blocks per CU must fit the 160 KiB LDS");
@@ -156,14 +156,12 @@ __host__ __device__ constexpr uint32_t at_or_before(int d, int b) {
 }
 
 __device__ inline uint32_t byte_of(const uint32_t *W, int idx) { return (W[idx >> 2] >> (8 * (idx & 3))) & 0xFFu; }
-// Seed-table lookups of the hot loop.  The two 2 KiB tables sit at LDS byte offsets 0 and 2048 (the kernel
-// has no static LDS, so the dynamic region starts at 0; checked at kernel entry).  The byte offset of an
-// entry is formed by ONE instruction -- v_lshlrev_b32_sdwa selects byte k of a window dword and shifts it
-// by 3 -- and the table base rides in the ds_read immediate.  Being inline asm, the offset is also opaque
-// to the optimizer: every base is looked up twice, 31 positions apart (entering and leaving the window),
-// and if the compiler saw one index it would fuse the two into a single ds_read2st64_b64 and keep the
-// second half alive for 31 positions (256 VGPRs, one wave per SIMD).
-typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+// Seed look-ups of the hot loop.  The two 2 KiB tables sit at LDS byte offsets 0 (IN pairs) and 2048 (OUT
+// pairs); the kernel has no static LDS, so the dynamic region starts at 0 (checked at kernel entry).  The byte
+// offset of a base's entries is formed ONCE, when the base enters the window, by one v_lshlrev_b32_sdwa (byte
+// select + x8); its IN pair is read right away and its OUT pair l positions later with the same offset
+// register and the table base in the ds_read immediate.  (Reading both pairs at once would be one LDS
+// instruction fewer, but the 4-register result tuple then stays pinned for ~40 positions: 256 VGPRs + spills.)
 template <int BYTE>
 __device__ __forceinline__ uint32_t byte_x8(uint32_t w) {
     uint32_t off;
@@ -173,19 +171,14 @@ __device__ __forceinline__ uint32_t byte_x8(uint32_t w) {
     if constexpr (BYTE == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(3u), "v"(w));
     return off;
 }
-template <int IDX, int TABLE_OFF, int NW>
-__device__ __forceinline__ uint2 lut(const uint32_t (&W)[NW]) {
-    const uint32_t off = byte_x8<IDX & 3>(W[IDX >> 2]);
-    const unsigned long long v = *reinterpret_cast<lds_cu64 *>(off + TABLE_OFF); // ds_read_b64 v, off offset:TABLE_OFF
+template <int TABLE_OFF>
+__device__ __forceinline__ uint2 seed_pair(uint32_t off) { // ds_read_b64 v, off offset:TABLE_OFF
+    typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+    const unsigned long long v = *reinterpret_cast<lds_cu64 *>(off + TABLE_OFF);
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
-template <int N, int BASE, int TABLE_OFF, int NW, int J = 0>
-__device__ __forceinline__ void lut_row(uint2 *dst, const uint32_t (&W)[NW]) { // dst[j] = table[byte BASE+j], j < N
-    if constexpr (J < N) {
-        dst[J] = lut<BASE + J, TABLE_OFF>(W);
-        lut_row<N, BASE, TABLE_OFF, NW, J + 1>(dst, W);
-    }
-}
+__device__ __forceinline__ uint2 tab_in(const uint2 *tab, uint32_t c) { return tab[c]; }
+__device__ __forceinline__ uint2 tab_out(const uint2 *tab, uint32_t c) { return tab[256 + c]; }
 
 // ------------------------------------------------------------------------------------------------
 // Hash loop, compile-time l, NP 16-byte pieces per lane.  Lane q owns hash positions
@@ -203,87 +196,91 @@ __device__ __forceinline__ void hit_track(uint32_t hv, uint32_t bound, uint32_t 
         : "vcc");
 }
 
+// Step s of the lane's stream (s = 0 .. T+L-1, all compile-time): base s enters the window; for s >= L the
+// l-mer at position p = s - L is complete, so it is tested and then rolled forward with OUT[p], IN[s].
+template <int L, int T, int S, class WL>
+__device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], uint32_t (&A)[T + L], uint2 (&EI)[T + L],
+                                           uint2 (&EO)[T], uint32_t &fh, uint32_t &rh, uint32_t &cap, uint32_t &bits,
+                                           uint32_t bound, uint8_t *hmb, WL &Sx, int lane) {
+    if constexpr (S < T + L - 1) {
+        // seeds are fetched 8 steps ahead of their use, a group of 8 at a time
+        if constexpr (S % 8 == 0) {
+            __builtin_amdgcn_sched_barrier(0); // bound the look-ahead: later groups must not be hoisted above this point
+            constexpr int G = S + 8; // first base of the group entering 8 steps from now
+            if constexpr (G % 16 == 0 && G > 0) { // the group starts a new 16-byte piece: slide the 32-byte window
+                W[0] = W[4]; W[1] = W[5]; W[2] = W[6]; W[3] = W[7];
+                const uint4 v = src[G / 16 + 1];
+                W[4] = v.x; W[5] = v.y; W[6] = v.z; W[7] = v.w;
+            }
+            constexpr int WB = (G % 16); // offset of the group inside the window
+#define S2K_IN(J)                                                          \
+    if constexpr (G + J < T + L - 1) {                                     \
+        A[G + J] = byte_x8<(WB + J) & 3>(W[(WB + J) >> 2]);                \
+        EI[G + J] = seed_pair<0>(A[G + J]);                                \
+    }
+            S2K_IN(0) S2K_IN(1) S2K_IN(2) S2K_IN(3) S2K_IN(4) S2K_IN(5) S2K_IN(6) S2K_IN(7)
+#undef S2K_IN
+            constexpr int H = S + 8 - L; // first base of the group leaving 8 steps from now
+#define S2K_OUT(J)                                                         \
+    if constexpr (H + J >= 0 && H + J < T - 1) EO[H + J] = seed_pair<2048>(A[H + J]);
+            S2K_OUT(0) S2K_OUT(1) S2K_OUT(2) S2K_OUT(3) S2K_OUT(4) S2K_OUT(5) S2K_OUT(6) S2K_OUT(7)
+#undef S2K_OUT
+        }
+        if constexpr (S < L) { // warm-up: first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174)
+            fh = __builtin_rotateleft32(fh, 1) ^ EI[S].x;
+            rh = __builtin_rotateright32(rh, 1) ^ EI[S].y;
+        } else {
+            constexpr int P = S - L;
+            const uint32_t hv = fh < rh ? fh : rh;                              // canonical (src/nthash_hpc.rs:276)
+            hit_track(hv, bound, cap, bits);                                    // hv <= bound (src/nthash_hpc.rs:277 / src/lib.rs:228)
+            fh = __builtin_rotateleft32(fh, 1) ^ EO[P].x ^ EI[S].x;             // src/nthash_hpc.rs:245
+            rh = __builtin_rotateright32(rh, 1) ^ EO[P].y ^ EI[S].y;            // src/nthash_hpc.rs:247-249
+            if constexpr (P % 8 == 7) {
+                hmb[P / 8] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
+                Sx.caps[P / 8][lane] = cap;
+                bits = 0;
+            }
+        }
+        hash_steps<L, T, S + 1>(src, W, A, EI, EO, fh, rh, cap, bits, bound, hmb, Sx, lane);
+    } else { // last position: test only, nothing left to roll into
+        const uint32_t hv = fh < rh ? fh : rh;
+        hit_track(hv, bound, cap, bits);
+        hmb[(T - 1) / 8] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
+        Sx.caps[(T - 1) / 8][lane] = cap;
+    }
+}
+
 template <int L, int NP, class WL>
-__device__ __forceinline__ void hash_loop_static(const uint8_t *D, const uint2 *__restrict__ t_in,
-                                                 const uint2 *__restrict__ t_out, uint32_t bound, int lane, WL &S) {
-    // bytes [0, L+24) of the lane-relative stream must be resident while the NEXT half-piece's seeds are fetched
-    constexpr int NWP = (L + 24 + 15) / 16;
-    uint32_t W[NWP * 4];
-    const uint4 *src = reinterpret_cast<const uint4 *>(D + 16 * NP * lane);
-#pragma unroll
-    for (int p = 0; p < NWP; p++) {
-        uint4 v = src[p];
-        W[4 * p] = v.x; W[4 * p + 1] = v.y; W[4 * p + 2] = v.z; W[4 * p + 3] = v.w;
+__device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t bound, int lane, WL &S) {
+    constexpr int T = 16 * NP;
+    static_assert(L >= 9 && L <= 32, "the static schedule assumes 8 < l <= 32");
+    uint32_t W[8]; // 32-byte window over the lane's stream: pieces i, i+1
+    const uint4 *src = reinterpret_cast<const uint4 *>(D + T * lane);
+    {
+        const uint4 v0 = src[0], v1 = src[1];
+        W[0] = v0.x; W[1] = v0.y; W[2] = v0.z; W[3] = v0.w;
+        W[4] = v1.x; W[5] = v1.y; W[6] = v1.z; W[7] = v1.w;
     }
-    // seeds are fetched one 8-position half-piece ahead of their use, so that one LDS round trip is paid
-    // per 8 positions instead of per position (two waves per SIMD cannot hide a dependent ds_read per step)
-    uint2 sin[2][8], sout[2][8];
-    lut_row<8, L, 0>(sin[0], W);
-    lut_row<8, 0, 2048>(sout[0], W);
-    uint32_t fh = 0, rh = 0;
-    { // warm-up: first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174), seeds fetched in two batches
-        constexpr int H1 = L < 16 ? L : 16;
-        uint2 wi[H1];
-        lut_row<H1, 0, 0>(wi, W);
+    uint32_t A[T + L];
+    uint2 EI[T + L], EO[T];
+    A[0] = byte_x8<0>(W[0]); A[1] = byte_x8<1>(W[0]); A[2] = byte_x8<2>(W[0]); A[3] = byte_x8<3>(W[0]);
+    A[4] = byte_x8<0>(W[1]); A[5] = byte_x8<1>(W[1]); A[6] = byte_x8<2>(W[1]); A[7] = byte_x8<3>(W[1]);
 #pragma unroll
-        for (int i = 0; i < H1; i++) {
-            fh = __builtin_rotateleft32(fh, 1) ^ wi[i].x;
-            rh = __builtin_rotateright32(rh, 1) ^ wi[i].y;
-        }
-        if constexpr (L > 16) {
-            uint2 wj[L - 16];
-            lut_row<L - 16, 16, 0>(wj, W);
-#pragma unroll
-            for (int i = 0; i < L - 16; i++) {
-                fh = __builtin_rotateleft32(fh, 1) ^ wj[i].x;
-                rh = __builtin_rotateright32(rh, 1) ^ wj[i].y;
-            }
-        }
-    }
-    uint32_t cap = 0;
+    for (int i = 0; i < 8; i++) EI[i] = seed_pair<0>(A[i]);
+    uint32_t fh = 0, rh = 0, cap = 0, bits = 0;
     uint8_t *hmb = reinterpret_cast<uint8_t *>(S.hm[lane]);
-#pragma unroll
-    for (int hp = 0; hp < 2 * NP; hp++) {
-        const int cur = hp & 1, nxt = cur ^ 1;
-        const int wo = 8 * (hp & 1); // offset of this half-piece inside the window (window starts at piece hp/2)
-        if (hp + 1 < 2 * NP) {
-            if (wo == 0) {
-                lut_row<8, 8 + L, 0>(sin[nxt], W);
-                lut_row<8, 8, 2048>(sout[nxt], W);
-            } else {
-                lut_row<8, 16 + L, 0>(sin[nxt], W);
-                lut_row<8, 16, 2048>(sout[nxt], W);
-            }
-        }
-        uint32_t bits = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint32_t hv = fh < rh ? fh : rh;                      // canonical (src/nthash_hpc.rs:276)
-            hit_track(hv, bound, cap, bits);                      // hv <= bound (src/nthash_hpc.rs:277 / src/lib.rs:228)
-            fh = __builtin_rotateleft32(fh, 1) ^ sout[cur][j].x ^ sin[cur][j].x;  // src/nthash_hpc.rs:245
-            rh = __builtin_rotateright32(rh, 1) ^ sout[cur][j].y ^ sin[cur][j].y; // src/nthash_hpc.rs:247-249
-        }
-        hmb[hp] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-        S.caps[hp][lane] = cap;
-        if ((hp & 1) && hp + 1 < 2 * NP) { // slide the window by one piece
-#pragma unroll
-            for (int i = 0; i < (NWP - 1) * 4; i++) W[i] = W[i + 4];
-            uint4 v = src[(hp >> 1) + NWP];
-            W[4 * NWP - 4] = v.x; W[4 * NWP - 3] = v.y; W[4 * NWP - 2] = v.z; W[4 * NWP - 1] = v.w;
-        }
-    }
+    hash_steps<L, T, 0>(src, W, A, EI, EO, fh, rh, cap, bits, bound, hmb, S, lane);
 }
 
 // Same loop for a run-time l (1..64): bytes are fetched one by one from LDS.  Slower; only l values
 // without a static instantiation come here.
 template <class WL>
-__device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 *__restrict__ t_in,
-                                         const uint2 *__restrict__ t_out, uint32_t bound, int lane, WL &S,
+__device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 *__restrict__ tab, uint32_t bound, int lane, WL &S,
                                          uint32_t l, int np) {
     const uint8_t *q = D + 16 * np * lane;
     uint32_t fh = 0, rh = 0;
     for (uint32_t i = 0; i < l; i++) {
-        uint2 ti = t_in[q[i]];
+        uint2 ti = tab_in(tab, q[i]);
         fh = __builtin_rotateleft32(fh, 1) ^ ti.x;
         rh = __builtin_rotateright32(rh, 1) ^ ti.y;
     }
@@ -294,8 +291,8 @@ __device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 
         bool hit = hv <= bound;
         cap = hit ? hv : cap;
         bits = (bits << 1) | (hit ? 1u : 0u);
-        uint2 to = t_out[q[pos]];
-        uint2 ti = t_in[q[pos + l]];
+        uint2 to = tab_out(tab, q[pos]);
+        uint2 ti = tab_in(tab, q[pos + l]);
         fh = __builtin_rotateleft32(fh, 1) ^ to.x ^ ti.x;
         rh = __builtin_rotateright32(rh, 1) ^ to.y ^ ti.y;
         if ((pos & 7) == 7) {
@@ -309,22 +306,22 @@ __device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 
 // Everything below is force-inlined into the kernel so that the LDS operands keep their address space
 // (a generic pointer costs a 64-bit add, a null compare and a select per table lookup).
 template <int L, bool HPC, class WL>
-__device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *t_in, const uint2 *t_out, uint32_t bound,
+__device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, uint32_t bound,
                                            int lane, WL &S, uint32_t l, int np) {
     if constexpr (L > 0) {
         if constexpr (!HPC) {
-            hash_loop_static<L, 9>(D, t_in, t_out, bound, lane, S); // raw tiles always span 9 pieces per lane
+            hash_loop_static<L, 9>(D, bound, lane, S); // raw tiles always span 9 pieces per lane
         } else {
             switch (np) { // wave-uniform: the compacted tile is shorter than the raw one
-            case 1: hash_loop_static<L, 1>(D, t_in, t_out, bound, lane, S); break;
-            case 3: hash_loop_static<L, 3>(D, t_in, t_out, bound, lane, S); break;
-            case 5: hash_loop_static<L, 5>(D, t_in, t_out, bound, lane, S); break;
-            case 7: hash_loop_static<L, 7>(D, t_in, t_out, bound, lane, S); break;
-            default: hash_loop_static<L, 9>(D, t_in, t_out, bound, lane, S); break;
+            case 1: hash_loop_static<L, 1>(D, bound, lane, S); break;
+            case 3: hash_loop_static<L, 3>(D, bound, lane, S); break;
+            case 5: hash_loop_static<L, 5>(D, bound, lane, S); break;
+            case 7: hash_loop_static<L, 7>(D, bound, lane, S); break;
+            default: hash_loop_static<L, 9>(D, bound, lane, S); break;
             }
         }
     } else {
-        hash_loop_dynamic(D, t_in, t_out, bound, lane, S, l, np);
+        hash_loop_dynamic(D, tab, bound, lane, S, l, np);
     }
 }
 
@@ -543,7 +540,7 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
 // Dense phase of one tile: hit bitmasks -> validated, ordered minimizer records.  Returns the number of
 // records (tile_cnt) and sets `base` (tile_rec_off).  See the file header for the idea.
 template <int L, bool HPC, class WL>
-__device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const uint2 *t_in, const uint2 *t_out,
+__device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const uint2 *tab,
                                                 const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t t,
                                                 uint64_t t0, uint32_t tile_len, uint32_t nh, uint32_t halo_n,
                                                 uint32_t Tq, uint32_t l, uint32_t r0, uint32_t r1, uint64_t bpos0,
@@ -703,7 +700,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 for (int i = 0; i < L; i++) by[i] = q[i];
                 uint2 ti[L];
 #pragma unroll
-                for (int i = 0; i < L; i++) ti[i] = t_in[by[i]]; // t_in[c] = {h[c], rotl(rc[c], l-1)}
+                for (int i = 0; i < L; i++) ti[i] = tab_in(tab, by[i]); // IN pair = {h[c], rotl(rc[c], l-1)}
 #pragma unroll
                 for (int i = 0; i < L; i++) {
                     f ^= rotl32(ti[i].x, L - 1 - i);
@@ -711,7 +708,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 }
             } else {
                 for (uint32_t i = 0; i < l; i++) {
-                    const uint2 ti = t_in[q[i]];
+                    const uint2 ti = tab_in(tab, q[i]);
                     f ^= rotl32(ti.x, l - 1 - i);
                     r ^= rotr32(ti.y, l - 1 - i);
                 }
@@ -848,8 +845,7 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
     uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     using WL = WaveLdsT<HPC>;
-    uint2 *t_in = reinterpret_cast<uint2 *>(smem);
-    uint2 *t_out = t_in + 256;
+    uint2 *tab = reinterpret_cast<uint2 *>(smem);
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap(); // lut() assumes it
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t l = L > 0 ? (uint32_t)L : sem.l;
@@ -857,8 +853,8 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
         // Hpc tiles carry read-start marks in bit 7 (input is 7-bit there), so the table ignores it
         uint32_t cc = HPC ? (c & 0x7F) : c;
         uint32_t h = seed_h_scalar(cc), r = seed_rc_scalar(cc);
-        t_in[c] = make_uint2(h, rotl32(r, l - 1));
-        t_out[c] = make_uint2(rotl32(h, l), rotr32(r, 1));
+        tab[c] = make_uint2(h, rotl32(r, l - 1));
+        tab[256 + c] = make_uint2(rotl32(h, l), rotr32(r, 1));
     }
     __syncthreads(); // the only workgroup barrier; waves are independent from here on
     WL &S = *reinterpret_cast<WL *>(smem + TABLE_BYTES + (size_t)w * sizeof(WL));
@@ -980,11 +976,11 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
         uint64_t base = 0;
         if (nh != 0 && sem.enabled) {
             // ---- the hot loop ------------------------------------------------------------------------------
-            if (!(sem.dbg_skip & 1)) hash_stage<L, HPC>(D, t_in, t_out, sem.bound_le, lane, S, l, np);
+            if (!(sem.dbg_skip & 1)) hash_stage<L, HPC>(D, tab, sem.bound_le, lane, S, l, np);
             wave_sync();
             S2K_STAMP(2); // hash loop
             if (!(sem.dbg_skip & 2))
-                N = dense_phase<L, HPC>(S, D, t_in, t_out, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
+                N = dense_phase<L, HPC>(S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
                                      rs0, lane, rec, pool_cursor, mn_cnt, counts, base, sem, ph, stamp);
             S2K_STAMP(5); // rounds
         }
