@@ -205,7 +205,6 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], u
     if constexpr (S < T + L - 1) {
         // seeds are fetched 8 steps ahead of their use, a group of 8 at a time
         if constexpr (S % 8 == 0) {
-            __builtin_amdgcn_sched_barrier(0); // bound the look-ahead: later groups must not be hoisted above this point
             constexpr int G = S + 8; // first base of the group entering 8 steps from now
             if constexpr (G % 16 == 0 && G > 0) { // the group starts a new 16-byte piece: slide the 32-byte window
                 W[0] = W[4]; W[1] = W[5]; W[2] = W[6]; W[3] = W[7];
@@ -493,11 +492,12 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
 // ~3.4k cycles per round of 64 hits).
 template <class WL>
 __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l, uint32_t R, uint32_t halo_n,
-                                            uint32_t Tq, uint32_t &raw_x, uint32_t &raw_e) {
+                                            uint32_t Tq, uint32_t rcpTq, uint32_t &raw_x, uint32_t &raw_e) {
     const uint32_t y = x + l;
     const bool y_in = y < R;
     const uint32_t yy = y_in ? y : x; // look-up 2 degenerates to look-up 1 when x + l lies after the tile
-    const uint32_t q1 = x / Tq, q2 = yy / Tq;
+    (void)Tq;
+    const uint32_t q1 = __umulhi(x, rcpTq), q2 = __umulhi(yy, rcpTq);
     uint32_t lo1 = S.hl[q1], hi1 = q1 < 63 ? S.hl[q1 + 1] : 63u;
     uint32_t lo2 = S.hl[q2], hi2 = q2 < 63 ? S.hl[q2 + 1] : 63u;
     // three candidates beyond lo at once; a wider bracket (long homopolymers: raw lanes without heads) loops
@@ -553,6 +553,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
     //     same read, src/nthash_hpc.rs:265-267).  The first read start at or after the tile end (or the
     //     end of the stream) is the one external boundary.
     const uint32_t wclr = HPC ? l : l - 1;
+    const uint32_t rcpTq = 0xFFFFFFFFu / Tq + 1u; // x / Tq == umulhi(x, rcpTq) for x < 2^16 (Tq <= 144)
     if constexpr (HPC) { // hint table for the back-map: owner raw lane of the first run head of every hash lane
         const uint32_t xq = Tq * (uint32_t)lane;
         uint32_t o = 0;
@@ -740,88 +741,103 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
         const uint32_t bn = N - b0 < (uint32_t)LISTCAP ? N - b0 : (uint32_t)LISTCAP;
         auto rounds = [&](auto many_c) {
         constexpr bool MANY = decltype(many_c)::value;
-        for (uint32_t k0 = 0; k0 < bn; k0 += 64) {
-            const uint32_t kk = k0 + lane;
-            const bool act = kk < bn;
-            uint32_t x = 0, hv = 0;
-            bool need_re = false;
-            if (act) {
-                x = S.list[kk];
-                const uint32_t o = x / Tq, bit = x - o * Tq, piece = bit >> 3;
-                const uint32_t pbyte = reinterpret_cast<const uint8_t *>(S.hm[o])[piece];
-                // the kept hash belongs to the piece's last raw hit; pieces cut by nh may hold a stale one
-                need_re = (pbyte >> ((bit & 7) + 1)) != 0 || (Tq * o + 8 * piece + 8 > nh);
-                hv = S.caps[piece][o];
+        constexpr int U = 2; // hits per lane per iteration: the LDS round trips of the two overlap
+        for (uint32_t k0 = 0; k0 < bn; k0 += 64 * U) {
+            uint32_t kk[U], x[U], hv[U], rid[U];
+            bool act[U], need_re[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                kk[u] = k0 + 64 * u + lane;
+                act[u] = kk[u] < bn;
+                x[u] = hv[u] = rid[u] = 0;
+                need_re[u] = false;
+                if (act[u]) {
+                    x[u] = S.list[kk[u]];
+                    const uint32_t o = __umulhi(x[u], rcpTq), bit = x[u] - o * Tq, piece = bit >> 3; // o = x / Tq
+                    const uint32_t pbyte = reinterpret_cast<const uint8_t *>(S.hm[o])[piece];
+                    // the kept hash belongs to the piece's last raw hit; pieces cut by nh may hold a stale one
+                    need_re[u] = (pbyte >> ((bit & 7) + 1)) != 0 || (Tq * o + 8 * piece + 8 > nh);
+                    hv[u] = S.caps[piece][o];
+                }
             }
             // hits that were not the last raw hit of their piece (~7 %) have no kept hash: queue them; one lane
             // per queued hit re-derives it from the l bytes (closed form, src/nthash_hpc.rs:144,168)
-            uint64_t jobs = __ballot(need_re);
-            if (sem.dbg_skip & 8) ph[7] += (uint64_t)__popcll(jobs);
-            if (sem.dbg_skip & 64) jobs = 0;
-            if (jobs) {
-                const uint32_t nj = (uint32_t)__popcll(jobs);
-                if (njobs + nj > 64) { // wave-uniform
-                    flush_jobs();
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                uint64_t jobs = __ballot(need_re[u]);
+                if (sem.dbg_skip & 8) ph[7] += (uint64_t)__popcll(jobs);
+                if (sem.dbg_skip & 64) jobs = 0;
+                if (jobs) {
+                    const uint32_t nj = (uint32_t)__popcll(jobs);
+                    if (njobs + nj > 64) flush_jobs(); // wave-uniform
+                    if (need_re[u]) {
+                        const uint32_t q = njobs + (uint32_t)__popcll(jobs & ((1ull << lane) - 1ull));
+                        S.jobx[q] = (uint16_t)x[u];
+                        S.jobslot[q] = b0 + kk[u];
+                    }
+                    njobs += nj;
                 }
-                if (need_re) {
-                    const uint32_t q = njobs + (uint32_t)__popcll(jobs & ((1ull << lane) - 1ull));
-                    S.jobx[q] = (uint16_t)x;
-                    S.jobslot[q] = b0 + kk;
-                }
-                njobs += nj;
             }
             S2K_STAMP(8); // round: list read, kept hash, job queueing
-            uint32_t rid = 0;
-            if (act) {
-                uint64_t p, e1; // stream position of the l-mer start; position of the last base that belongs to it
-                if constexpr (HPC) {
-                    uint32_t rp = 0, re = 0;
-                    hpc_rawpos2(S, x, l, nh, halo_n, Tq, rp, re); // head x + l exists: the hit survived validation
-                    p = t0 + rp;
-                    e1 = t0 + re - 1; // st[p+l] - 1, src/nthash_hpc.rs:281
-                } else {
-                    p = t0 + x;
-                    e1 = p + l - 1; // src/lib.rs:226
-                }
-                S2K_STAMP(9); // round: back-map
-                uint64_t rstart;
-                if constexpr (!MANY) {
-                    uint32_t c = 0;
-                    for (uint32_t i = 0; i < nb; i++) c += (S.hb[i] <= (int32_t)x); // wave-uniform trip count, LDS broadcast
-                    rid = r0 + c;
-                    rstart = S.rs[c];
-                } else {
-                    // > 62 reads start in this tile: search the read table itself.  The volatile asm keeps these
-                    // (cold) loads from being merged into the common path's wait counters.
-                    uint32_t lo = r0, hi = r1;
-                    while (lo < hi) {
-                        uint32_t mid = lo + (hi - lo + 1) / 2;
-                        if (read_off[mid] <= p) lo = mid;
-                        else hi = mid - 1;
+            uint64_t p[U], e1[U]; // stream position of the l-mer start; position of the last base that belongs to it
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                p[u] = e1[u] = 0;
+                if (act[u]) {
+                    if constexpr (HPC) {
+                        uint32_t rp = 0, re = 0;
+                        hpc_rawpos2(S, x[u], l, nh, halo_n, Tq, rcpTq, rp, re); // head x + l exists: the hit survived validation
+                        p[u] = t0 + rp;
+                        e1[u] = t0 + re - 1; // st[p+l] - 1, src/nthash_hpc.rs:281
+                    } else {
+                        p[u] = t0 + x[u];
+                        e1[u] = p[u] + l - 1; // src/lib.rs:226
                     }
-                    rid = lo;
-                    rstart = read_off[rid];
                 }
-                const uint64_t slot = base + b0 + kk;
-                if (!(sem.dbg_skip & 16)) {
-                rec.j[slot] = (uint32_t)(p - rstart);
-                rec.jend[slot] = (uint32_t)(e1 - rstart);
-                if (!need_re) rec.hash[slot] = hv;
-                rec.rid[slot] = rid;
+            }
+            S2K_STAMP(9); // round: back-map
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (act[u]) {
+                    uint64_t rstart;
+                    if constexpr (!MANY) {
+                        uint32_t c = 0;
+                        for (uint32_t i = 0; i < nb; i++) c += (S.hb[i] <= (int32_t)x[u]); // wave-uniform trip count, LDS broadcast
+                        rid[u] = r0 + c;
+                        rstart = S.rs[c];
+                    } else { // > 62 reads start in this tile: search the read table itself
+                        uint32_t lo = r0, hi = r1;
+                        while (lo < hi) {
+                            uint32_t mid = lo + (hi - lo + 1) / 2;
+                            if (read_off[mid] <= p[u]) lo = mid;
+                            else hi = mid - 1;
+                        }
+                        rid[u] = lo;
+                        rstart = read_off[lo];
+                    }
+                    const uint64_t slot = base + b0 + kk[u];
+                    if (!(sem.dbg_skip & 16)) {
+                        rec.j[slot] = (uint32_t)(p[u] - rstart);
+                        rec.jend[slot] = (uint32_t)(e1[u] - rstart);
+                        if (!need_re[u]) rec.hash[slot] = hv[u];
+                        rec.rid[slot] = rid[u];
+                    }
                 }
             }
             S2K_STAMP(10); // round: read lookup + stores
-            // per-read minimizer counts: one atomic per (round, read)
-            uint64_t remm = MANY ? __ballot(act) : 0ull; // the common case counted per tile above
-            if (sem.dbg_skip & 32) remm = 0;
-            while (remm) {
-                const int z = __builtin_ctzll(remm);
-                const uint32_t rz = bcast(rid, z);
-                const uint64_t same = __ballot(act && rid == rz);
-                if (lane == z) atomicAdd(&mn_cnt[rz], (uint32_t)__popcll(same));
-                remm &= ~same;
+            if constexpr (MANY) { // per-read minimizer counts: one atomic per (round, read); the common case is counted per tile above
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    uint64_t remm = __ballot(act[u]);
+                    while (remm) {
+                        const int z = __builtin_ctzll(remm);
+                        const uint32_t rz = bcast(rid[u], z);
+                        const uint64_t same = __ballot(act[u] && rid[u] == rz);
+                        if (lane == z) atomicAdd(&mn_cnt[rz], (uint32_t)__popcll(same));
+                        remm &= ~same;
+                    }
+                }
             }
-            S2K_STAMP(11); // round: per-read counts
         }
         };
         // > 62 reads starting in one tile take the variant that searches the read table itself; keeping it a
