@@ -163,6 +163,24 @@ s2k_status s2k_enable_timing(s2k_ctx *ctx, int on);
  * durations (`which` as above), and the number of calls: average kernel duration over a timed region. */
 s2k_status s2k_timing_total(s2k_ctx *ctx, int which, double *ms_sum, uint32_t *n_calls);
 
+/* ---- FASTA / FASTQ ingest and batching (next row of SURVEY.md 8f) --------------------------------------
+ * Counterpart of the reference's file mode: rust_parallelfastx::parallel_fastx(file, threads, task) feeding one
+ * KminmersIterator per record (src/main.rs:51-83).  Records are parsed on the host into batches
+ * (bases back to back + read_off) held in pinned memory, so a batch is what s2k_extract consumes. */
+typedef struct s2k_fastx s2k_fastx; /* opaque reader */
+/* Opens a FASTA (multi-line allowed) or FASTQ (4-line) file; the format is detected from the first byte. */
+s2k_fastx *s2k_fastx_open(const char *path, s2k_status *status);
+/* Parses the next records until `max_bases` bases or `max_reads` reads are collected (at least one record).
+ * *bases / *read_off point into reader-owned buffers, valid until the next call; *n_reads == 0 at end of file. */
+s2k_status s2k_fastx_next(s2k_fastx *rd, uint64_t max_bases, uint64_t max_reads, const uint8_t **bases,
+                          const uint64_t **read_off, uint64_t *n_reads);
+void s2k_fastx_close(s2k_fastx *rd);
+/* Streams a whole file through the GPU in batches of ~batch_bases (parsing batch i+1 overlaps the kernels of
+ * batch i) and returns the totals; k-min-mers are produced in HBM and counted, like the reference's demo task
+ * (src/main.rs:65-76).  `seconds` receives the wall time of the whole call (file read included). */
+s2k_status s2k_run_file(s2k_ctx *ctx, const char *path, const s2k_params *params, uint64_t batch_bases,
+                        s2k_counts *totals, double *seconds);
+
 #ifdef __cplusplus
 }
 #endif

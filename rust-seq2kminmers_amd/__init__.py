@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libs2k.so")
 ABI_SYMBOLS = [
     "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_strerror",
     "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
-    "s2k_hpc_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total",
+    "s2k_hpc_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file",
 ]
 
 
@@ -116,6 +116,12 @@ def load_library(path=None):
     L.s2k_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.s2k_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.s2k_timing_total.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.s2k_fastx_open.restype = C.c_void_p
+    L.s2k_fastx_open.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    L.s2k_fastx_next.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.s2k_fastx_close.argtypes = [C.c_void_p]
+    L.s2k_fastx_close.restype = None
+    L.s2k_run_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Params), C.c_uint64, C.POINTER(Counts), C.POINTER(C.c_double)]
     if path is None:
         _lib = L
     return L
@@ -241,12 +247,57 @@ class Engine:
     def synth_bases_device(self, seed, first_base, n, d_ptr):
         self._check(self.lib.s2k_synth_bases_device(self.ctx, seed, first_base, n, C.c_void_p(d_ptr)))
 
+    def run_file(self, path, l, k, density, mode=HashMode.Regular, batch_bases=256 << 20, flags=0):
+        """FASTA/FASTQ file -> totals; the file mode of the reference's CLI (src/main.rs:51-83) on the GPU."""
+        p = Params(int(l), int(k), float(density), int(mode), int(flags))
+        cnt, sec = Counts(), C.c_double(0)
+        self._check(self.lib.s2k_run_file(self.ctx, os.fsencode(path), C.byref(p), batch_bases, C.byref(cnt), C.byref(sec)))
+        d = cnt.as_dict()
+        d["seconds"] = float(sec.value)
+        return d
+
     def hpc_device(self, d_bases, d_read_off, n_reads, n_bases, d_hpc_off, d_hpc, d_pos, capacity):
         n = C.c_uint64(0)
         st = self.lib.s2k_hpc_device(self.ctx, C.c_void_p(d_bases), C.c_void_p(d_read_off), n_reads, n_bases,
                                      C.c_void_p(d_hpc_off), C.c_void_p(d_hpc or 0), C.c_void_p(d_pos or 0), capacity, C.byref(n))
         self._check(st)
         return int(n.value)
+
+
+class FastxReader:
+    """FASTA/FASTQ batches (bases back to back + read_off), the front-end that replaces parallel_fastx
+    (src/main.rs:79).  Host-only: works without a GPU."""
+
+    def __init__(self, path):
+        self.lib = load_library()
+        st = C.c_int(0)
+        self.rd = self.lib.s2k_fastx_open(os.fsencode(path), C.byref(st))
+        if not self.rd:
+            raise S2kError(st.value, "cannot open %s" % path)
+
+    def next_batch(self, max_bases=256 << 20, max_reads=0):
+        """-> (bases u8 copy, read_off u64 copy) or None at end of file"""
+        b, o, n = C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+        st = self.lib.s2k_fastx_next(self.rd, max_bases, max_reads, C.byref(b), C.byref(o), C.byref(n))
+        if st != 0:
+            raise S2kError(st, "malformed FASTA/FASTQ record")
+        if n.value == 0:
+            return None
+        off = np.ctypeslib.as_array(C.cast(o, _u64p), shape=(n.value + 1,)).copy()
+        nb = int(off[-1])
+        bases = np.ctypeslib.as_array(C.cast(b, _u8p), shape=(max(nb, 1),))[:nb].copy()
+        return bases, off
+
+    def close(self):
+        if getattr(self, "rd", None):
+            self.lib.s2k_fastx_close(self.rd)
+            self.rd = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _default_engine = None

@@ -1,0 +1,136 @@
+"""FASTA/FASTQ ingest + batching (counterpart of parallel_fastx + src/main.rs:51-83).
+The parser is host code (CPU tier); the file driver runs the GPU path and is checked against the oracle."""
+import numpy as np
+import pytest
+
+from s2k_loader import import_package
+
+pkg = import_package()
+
+
+def _reads(rng, n, maxlen=3000):
+    return [bytes(np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5 if i % 7 == 0 else 4, size=int(rng.integers(0, maxlen)))])
+            for i in range(n)]
+
+
+def _write_fasta(path, reads, width=0, crlf=False, trailing_newline=True):
+    nl = "\r\n" if crlf else "\n"
+    with open(path, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write((">read%d some description%s" % (i, nl)).encode())
+            s = r.decode()
+            if width:
+                lines = [s[j:j + width] for j in range(0, len(s), width)] or [""]
+            else:
+                lines = [s]
+            body = nl.join(lines)
+            last = i == len(reads) - 1
+            f.write((body + ("" if last and not trailing_newline else nl)).encode())
+
+
+def _write_fastq(path, reads):
+    with open(path, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+
+
+def _collect(path, max_bases, max_reads=0):
+    rd = pkg.FastxReader(str(path))
+    out = []
+    nbatches = 0
+    while True:
+        b = rd.next_batch(max_bases, max_reads)
+        if b is None:
+            break
+        nbatches += 1
+        bases, off = b
+        for r in range(len(off) - 1):
+            out.append(bases[int(off[r]):int(off[r + 1])].tobytes())
+    rd.close()
+    return out, nbatches
+
+
+@pytest.mark.parametrize("width,crlf,trail", [(0, False, True), (60, False, True), (70, True, True), (0, False, False), (13, False, False)])
+def test_fasta_parsing(tmp_path, width, crlf, trail):
+    rng = np.random.default_rng(1)
+    reads = _reads(rng, 57)
+    p = tmp_path / "x.fa"
+    _write_fasta(p, reads, width, crlf, trail)
+    got, nb = _collect(p, 20000)
+    assert got == reads and nb > 3
+    got, nb = _collect(p, 1 << 30)
+    assert got == reads and nb == 1
+    got, nb = _collect(p, 1 << 30, max_reads=5)
+    assert got == reads and nb == 12
+
+
+def test_fastq_parsing_and_errors(tmp_path):
+    rng = np.random.default_rng(2)
+    reads = _reads(rng, 33)
+    p = tmp_path / "x.fq"
+    _write_fastq(p, reads)
+    got, _ = _collect(p, 5000)
+    assert got == reads
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r1\nACGT\nIIII\n")  # missing '+' line
+    rd = pkg.FastxReader(str(bad))
+    with pytest.raises(pkg.S2kError):
+        rd.next_batch()
+    with pytest.raises(pkg.S2kError):
+        pkg.FastxReader(str(tmp_path / "does_not_exist.fa"))
+    empty = tmp_path / "empty.fa"
+    empty.write_bytes(b"")
+    assert _collect(empty, 100) == ([], 0)
+
+
+@pytest.mark.gpu
+def test_run_file_matches_oracle(tmp_path, oracle):
+    from oracle import s2k_oracle as so
+
+    rng = np.random.default_rng(3)
+    reads = _reads(rng, 400, maxlen=30000)
+    p = tmp_path / "reads.fa"
+    _write_fasta(p, reads, width=80)
+    bases, off = pkg.pack_reads(reads)
+    eng = pkg.Engine(0)
+    for mode, omode in ((pkg.HashMode.Regular, so.REGULAR), (pkg.HashMode.Hpc, so.HPC)):
+        ref = oracle.batch(bases, off, 31, 5, 0.01, omode)
+        mn = oracle.batch_minimizers(bases, off, 31, 0.01, omode)
+        for batch in (1 << 30, 300000):  # one batch / many batches (read order and totals must not depend on batching)
+            tot = eng.run_file(str(p), 31, 5, 0.01, mode, batch_bases=batch)
+            assert tot["n_reads"] == len(reads) and tot["n_bases"] == len(bases)
+            assert tot["n_kminmers"] == ref["n"] and tot["n_minimizers"] == mn["n"]
+            assert tot["xor_hash"] == int(np.bitwise_xor.reduce(ref["hash"]))
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_cli_demo_and_file_mode(tmp_path, oracle):
+    """src/main.rs:13-48 (demo) and :51-83 (file mode) through the C++ driver."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+    from oracle import s2k_oracle as so
+
+    exe = os.path.join(ROOT, "rust-seq2kminmers_amd", "csrc", "s2k_main")
+    demo = subprocess.run([exe], capture_output=True, text=True)
+    assert demo.returncode == 0, demo.stderr
+    seq = b"AACTGCACTGCACTGCACTGCACACTGCACTGCACTGCACTGCACACTGCACTGCACTGACTGCACTGCACTGCACTGCACTGCCTGC"
+    for name, omode in (("Regular", so.REGULAR), ("Simd", so.SIMD), ("Hpc", so.HPC), ("HpcSimd", so.HPCSIMD)):
+        ref = oracle.kminmers(seq, 28, 5, 0.1, omode)
+        block = demo.stdout.split("mode: %s\n" % name)[1].split("mode: ")[0]
+        lines = [x for x in block.splitlines() if x.startswith("kminmer:")]
+        assert len(lines) == len(ref["hash"])
+        for i, ln in enumerate(lines):
+            assert "hash: %d, start: %d, end: %d, offset: %d, rev: %s" % (int(ref["hash"][i]), int(ref["start"][i]), int(ref["end"][i]), i,
+                                                                           "true" if ref["rev"][i] else "false") in ln
+    rng = np.random.default_rng(5)
+    reads = _reads(rng, 100, maxlen=20000)
+    p = tmp_path / "r.fq"
+    _write_fastq(p, reads)
+    bases, off = pkg.pack_reads(reads)
+    ref = oracle.batch(bases, off, 31, 5, 0.01, so.REGULAR)
+    out = subprocess.run([exe, str(p)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "kminmers: %d " % ref["n"] in out.stdout and "FASTA to kminmers in" in out.stdout
