@@ -29,6 +29,7 @@
 //    the exact serial kernels).
 #include "s2k_dev.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace s2k {
@@ -1045,6 +1046,7 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
         int occ = 0;
         S2K_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64 * TW, lds));
         per_cu = occ < 1 ? 1 : occ;
+        if (const char *e = getenv("S2K_DEBUG_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu; // occupancy experiments
         n_cu = prop.multiProcessorCount;
     }
     uint64_t blocks = (n_tiles + TW - 1) / TW;
