@@ -145,7 +145,8 @@ __global__ __launch_bounds__(64 * KM_WAVES) void kminmer_kernel(
 // (where the k-1 records after the tile's last one almost always live), then all records of the pass plus those
 // k-1 "tail" records, then the per-read offsets; everything else runs out of registers and LDS.
 constexpr int KF_WAVES = 4;
-constexpr int KF_PASS = 256; // records per pass = 4 per lane
+constexpr int KF_U = 2;              // records per lane per pass
+constexpr int KF_PASS = 64 * KF_U;   // records per pass
 constexpr int KF_TAIL = 64;  // k - 1 <= 64
 
 __global__ __launch_bounds__(64 * KF_WAVES) void kminmer_kernel_fast(
@@ -202,10 +203,10 @@ __global__ __launch_bounds__(64 * KF_WAVES) void kminmer_kernel_fast(
     }
     uint64_t xacc = 0;
     for (uint32_t base = 0; base < cnt; base += KF_PASS) {
-        uint32_t j[4], je[4], hv[4], rid[4];
-        bool have[4];
+        uint32_t j[KF_U], je[KF_U], hv[KF_U], rid[KF_U];
+        bool have[KF_U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { // round trip 2: up to 256 records
+        for (int u = 0; u < KF_U; u++) { // round trip 2: up to 256 records
             const uint32_t i = base + 64 * u + lane;
             have[u] = i < cnt;
             j[u] = je[u] = hv[u] = rid[u] = 0;
@@ -216,9 +217,9 @@ __global__ __launch_bounds__(64 * KF_WAVES) void kminmer_kernel_fast(
                 rid[u] = rec.rid[roff + i];
             }
         }
-        uint64_t m0[4], m1[4], ko[4];
+        uint64_t m0[KF_U], m1[KF_U], ko[KF_U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { // round trip 3: per-read offsets (same address for most lanes)
+        for (int u = 0; u < KF_U; u++) { // round trip 3: per-read offsets (same address for most lanes)
             m0[u] = m1[u] = ko[u] = 0;
             if (have[u]) {
                 m0[u] = mn_off[rid[u]];
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void kminmer_kernel_fast(
             s_tje[w][lane] = tje;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < KF_U; u++) {
             s_x[w][64 * u + lane] = mix32(hv[u]);
             s_je[w][64 * u + lane] = je[u];
         }
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void kminmer_kernel_fast(
         }
         // entries inside the 256 but past the tile's last record: tail
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < KF_U; u++) {
             const uint32_t i = base + 64 * u + lane;
             if (!have[u] && i - cnt < K1) {
                 s_x[w][64 * u + lane] = s_tx[w][i - cnt];
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(64 * KF_WAVES) void kminmer_kernel_fast(
         }
         wave_sync();
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < KF_U; u++) {
             if (!have[u]) continue;
             const uint32_t i = base + 64 * u + lane;
             const uint64_t g = g0 + i;
