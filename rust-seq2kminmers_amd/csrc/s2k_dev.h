@@ -69,13 +69,14 @@ constexpr int XOR_SHARDS = 4096;
 constexpr int TILE_T = 144;              // bases per lane
 constexpr int TILE_BASES = 64 * TILE_T;  // 9216 bases per wave-tile
 
-// Orders LDS traffic between the lanes of ONE wave (no workgroup barrier: waves of a block run
-// independent tiles with different trip counts).  A wave's DS operations execute in program order, so
-// a wavefront-scope fence -- which only constrains the compiler and the wave's own waitcnts -- is enough.
+// Orders LDS traffic between the lanes of ONE wave (no workgroup barrier: waves of a block run independent
+// tiles with different trip counts).  A wave's DS operations execute in program order, so waiting for the
+// wave's own outstanding LDS operations (lgkmcnt) and stopping the compiler from moving memory accesses
+// across this point is enough.  Deliberately NOT a fence: a wavefront-scope fence also drains vmcnt, i.e.
+// it would stall on every global store / atomic / prefetch load in flight at each of the ~10 syncs per tile.
 __device__ inline void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 struct Records { // SoA pool of minimizer records written by the minimizer kernels

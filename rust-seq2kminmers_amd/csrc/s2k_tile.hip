@@ -973,21 +973,26 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
             np = need <= 1 ? 1 : need <= 3 ? 3 : need <= 5 ? 5 : need <= 7 ? 7 : 9;
         }
         S2K_STAMP(1); // hpc compaction
-        // ---- next tile's loads go out now and land while this tile is hashed -----------------------------
-        have_pre = false;
+        // ---- next tile's loads: issued before the hash loop (Regular: their latency hides under it) or right
+        //      after it (Hpc: 40 staging registers live across the hash loop spill there; the dense phase covers
+        //      most of the latency instead) -----------------------------------------------------------------------
         uint64_t bposn = ~0ull, rs0n = 0;
         uint32_t r0nn = 0, r1nn = 0;
-        if (t + n_waves < n_tiles) {
-            if (is_full(t + n_waves)) {
-                prefetch(t + n_waves);
-                have_pre = true;
+        auto issue_next = [&]() {
+            have_pre = false;
+            if (t + n_waves < n_tiles) {
+                if (is_full(t + n_waves)) {
+                    prefetch(t + n_waves);
+                    have_pre = true;
+                }
+                read_entries(r0n, bposn, rs0n);
+                if (t + 2 * n_waves < n_tiles) {
+                    r0nn = tile_read0[t + 2 * n_waves];
+                    r1nn = tile_read0[t + 2 * n_waves + 1];
+                }
             }
-            read_entries(r0n, bposn, rs0n);
-            if (t + 2 * n_waves < n_tiles) {
-                r0nn = tile_read0[t + 2 * n_waves];
-                r1nn = tile_read0[t + 2 * n_waves + 1];
-            }
-        }
+        };
+        if constexpr (!HPC) issue_next();
         const uint32_t Tq = 16 * np;
         uint32_t N = 0;
         uint64_t base = 0;
@@ -996,6 +1001,9 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
             if (!(sem.dbg_skip & 1)) hash_stage<L, HPC>(D, tab, sem.bound_le, lane, S, l, np);
             wave_sync();
             S2K_STAMP(2); // hash loop
+        }
+        if constexpr (HPC) issue_next();
+        if (nh != 0 && sem.enabled) {
             if (!(sem.dbg_skip & 2))
                 N = dense_phase<L, HPC>(S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
                                      rs0, lane, rec, pool_cursor, mn_cnt, counts, base, sem, ph, stamp);
