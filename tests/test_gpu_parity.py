@@ -266,3 +266,48 @@ def test_synthetic_config2_sample_properties(eng, oracle):
             s, e = int(a["km_off"][r]), int(a["km_off"][r + 1])
             assert (np.diff(a["start"][s:e].astype(np.int64)) > 0).all()
             assert (a["end"][s:e] > a["start"][s:e]).all() and int(a["end"][s:e].max(initial=0)) < L
+
+
+def _lognormal_lengths(rng, n, mean, sigma, lo, hi):
+    mu = np.log(mean) - sigma * sigma / 2
+    return np.clip(rng.lognormal(mu, sigma, size=n), lo, hi).astype(np.int64)
+
+
+def test_baseline_config3_ont_like_lengths(eng, oracle):
+    """BASELINE config 3 shape at oracle-checkable size: ONT-like reads, lengths lognormal(mean 20 kbp, sigma 0.5)
+    clipped to [1 k, 200 k]; tiles are cut independently of the ragged read lengths."""
+    rng = np.random.default_rng(31)
+    lens = _lognormal_lengths(rng, 160, 20000, 0.5, 1000, 200000)
+    reads = [rand_read(rng, int(n), hp=0.15) for n in lens]
+    for mode in SCALAR:
+        compare(eng, oracle, reads, 31, 10, 0.01, mode, expect_path=0, tag="C3-ont")
+
+
+def test_baseline_config4_hifi_like_hpc_backmap(eng, oracle):
+    """BASELINE config 4: HiFi-like reads N(15 k, 2 k), homopolymer-enriched (geometric run lengths, 0.1 % of runs
+    stretched to 20..3000 bases so that l+1 run starts overflow any fixed look-ahead), Hpc mode, every start/end
+    checked against the oracle."""
+    rng = np.random.default_rng(32)
+    reads = []
+    for _ in range(60):
+        n = int(max(2000, rng.normal(15000, 2000)))
+        runs = rng.geometric(0.5, size=n)  # mean run length 2
+        stretch = rng.random(n) < 0.001
+        runs[stretch] = rng.integers(20, 3000, size=int(stretch.sum()))
+        letters = rng.integers(0, 4, size=n)
+        letters[1:] = (letters[:-1] + 1 + rng.integers(0, 3, size=n - 1)) % 4  # consecutive runs differ... mostly
+        s = np.repeat(np.frombuffer(b"ACGT", dtype=np.uint8)[letters], runs)[:n]
+        reads.append(s.tobytes())
+    got = compare(eng, oracle, reads, 31, 10, 0.01, HM.Hpc, expect_path=0, tag="C4-hifi")
+    assert got["n"] > 0 and int((got["end"] - got["start"]).max()) > 500  # long runs really widen the spans
+    compare(eng, oracle, reads, 31, 10, 0.01, HM.Regular, expect_path=0, tag="C4-hifi-regular")
+
+
+def test_baseline_config5_mbp_contigs_sparse_density(eng, oracle):
+    """BASELINE config 5: chromosome-scale 1 Mbp contigs, d = 0.001 (bound 4 294 967): one read spans >100 tiles,
+    most waves emit almost nothing, k-min-mer windows span ~5 kbp = several tiles."""
+    rng = np.random.default_rng(33)
+    reads = [rand_read(rng, 1_000_000, hp=0.2) for _ in range(6)] + [rand_read(rng, 1_000_000)]
+    for mode in SCALAR:
+        got = compare(eng, oracle, reads, 31, 10, 0.001, mode, expect_path=0, tag="C5-contigs")
+        assert got["counts"]["hash_bound"] == 4294967
