@@ -41,6 +41,8 @@ constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window s
 constexpr int NPC = TILE_T / 8;                        // 18 capture pieces per lane
 constexpr int MAX_L_TILED = 64;
 constexpr int LISTCAP = 512;                           // hits handled per dense batch
+constexpr int REG_LA = 2;
+constexpr int HPC_LA = 2;                              // seed look-ahead (positions) of the Hpc hash loop: 8 spills there
 constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
 
 struct HpcLds {
@@ -199,14 +201,14 @@ __device__ __forceinline__ void hit_track(uint32_t hv, uint32_t bound, uint32_t 
 
 // Step s of the lane's stream (s = 0 .. T+L-1, all compile-time): base s enters the window; for s >= L the
 // l-mer at position p = s - L is complete, so it is tested and then rolled forward with OUT[p], IN[s].
-template <int L, int T, int S, class WL>
+template <int L, int T, int LA, int S, class WL>
 __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], uint32_t (&A)[T + L], uint2 (&EI)[T + L],
                                            uint2 (&EO)[T], uint32_t &fh, uint32_t &rh, uint32_t &cap, uint32_t &bits,
                                            uint32_t bound, uint8_t *hmb, WL &Sx, int lane) {
     if constexpr (S < T + L - 1) {
         // seeds are fetched 8 steps ahead of their use, a group of 8 at a time
-        if constexpr (S % 8 == 0) {
-            constexpr int G = S + 8; // first base of the group entering 8 steps from now
+        if constexpr (S % LA == 0) {
+            constexpr int G = S + LA; // first base of the group entering LA steps from now
             if constexpr (G % 16 == 0 && G > 0) { // the group starts a new 16-byte piece: slide the 32-byte window
                 W[0] = W[4]; W[1] = W[5]; W[2] = W[6]; W[3] = W[7];
                 const uint4 v = src[G / 16 + 1];
@@ -214,15 +216,15 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], u
             }
             constexpr int WB = (G % 16); // offset of the group inside the window
 #define S2K_IN(J)                                                          \
-    if constexpr (G + J < T + L - 1) {                                     \
+    if constexpr (J < LA && G + J < T + L - 1) {                          \
         A[G + J] = byte_x8<(WB + J) & 3>(W[(WB + J) >> 2]);                \
         EI[G + J] = seed_pair<0>(A[G + J]);                                \
     }
             S2K_IN(0) S2K_IN(1) S2K_IN(2) S2K_IN(3) S2K_IN(4) S2K_IN(5) S2K_IN(6) S2K_IN(7)
 #undef S2K_IN
-            constexpr int H = S + 8 - L; // first base of the group leaving 8 steps from now
+            constexpr int H = S + LA - L; // first base of the group leaving LA steps from now
 #define S2K_OUT(J)                                                         \
-    if constexpr (H + J >= 0 && H + J < T - 1) EO[H + J] = seed_pair<2048>(A[H + J]);
+    if constexpr (J < LA && H + J >= 0 && H + J < T - 1) EO[H + J] = seed_pair<2048>(A[H + J]);
             S2K_OUT(0) S2K_OUT(1) S2K_OUT(2) S2K_OUT(3) S2K_OUT(4) S2K_OUT(5) S2K_OUT(6) S2K_OUT(7)
 #undef S2K_OUT
         }
@@ -241,7 +243,7 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], u
                 bits = 0;
             }
         }
-        hash_steps<L, T, S + 1>(src, W, A, EI, EO, fh, rh, cap, bits, bound, hmb, Sx, lane);
+        hash_steps<L, T, LA, S + 1>(src, W, A, EI, EO, fh, rh, cap, bits, bound, hmb, Sx, lane);
     } else { // last position: test only, nothing left to roll into
         const uint32_t hv = fh < rh ? fh : rh;
         hit_track(hv, bound, cap, bits);
@@ -250,7 +252,7 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], u
     }
 }
 
-template <int L, int NP, class WL>
+template <int L, int NP, int LA, class WL>
 __device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t bound, int lane, WL &S) {
     constexpr int T = 16 * NP;
     static_assert(L >= 9 && L <= 32, "the static schedule assumes 8 < l <= 32");
@@ -264,12 +266,12 @@ __device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t boun
     uint32_t A[T + L];
     uint2 EI[T + L], EO[T];
     A[0] = byte_x8<0>(W[0]); A[1] = byte_x8<1>(W[0]); A[2] = byte_x8<2>(W[0]); A[3] = byte_x8<3>(W[0]);
-    A[4] = byte_x8<0>(W[1]); A[5] = byte_x8<1>(W[1]); A[6] = byte_x8<2>(W[1]); A[7] = byte_x8<3>(W[1]);
+    if constexpr (LA > 4) { A[4] = byte_x8<0>(W[1]); A[5] = byte_x8<1>(W[1]); A[6] = byte_x8<2>(W[1]); A[7] = byte_x8<3>(W[1]); }
 #pragma unroll
-    for (int i = 0; i < 8; i++) EI[i] = seed_pair<0>(A[i]);
+    for (int i = 0; i < LA; i++) EI[i] = seed_pair<0>(A[i]);
     uint32_t fh = 0, rh = 0, cap = 0, bits = 0;
     uint8_t *hmb = reinterpret_cast<uint8_t *>(S.hm[lane]);
-    hash_steps<L, T, 0>(src, W, A, EI, EO, fh, rh, cap, bits, bound, hmb, S, lane);
+    hash_steps<L, T, LA, 0>(src, W, A, EI, EO, fh, rh, cap, bits, bound, hmb, S, lane);
 }
 
 // Same loop for a run-time l (1..64): bytes are fetched one by one from LDS.  Slower; only l values
@@ -310,14 +312,14 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
                                            int lane, WL &S, uint32_t l, int np) {
     if constexpr (L > 0) {
         if constexpr (!HPC) {
-            hash_loop_static<L, 9>(D, bound, lane, S); // raw tiles always span 9 pieces per lane
+            hash_loop_static<L, 9, REG_LA>(D, bound, lane, S); // raw tiles always span 9 pieces per lane
         } else {
             switch (np) { // wave-uniform: the compacted tile is shorter than the raw one
-            case 1: hash_loop_static<L, 1>(D, bound, lane, S); break;
-            case 3: hash_loop_static<L, 3>(D, bound, lane, S); break;
-            case 5: hash_loop_static<L, 5>(D, bound, lane, S); break;
-            case 7: hash_loop_static<L, 7>(D, bound, lane, S); break;
-            default: hash_loop_static<L, 9>(D, bound, lane, S); break;
+            case 1: hash_loop_static<L, 1, HPC_LA>(D, bound, lane, S); break;
+            case 3: hash_loop_static<L, 3, HPC_LA>(D, bound, lane, S); break;
+            case 5: hash_loop_static<L, 5, HPC_LA>(D, bound, lane, S); break;
+            case 7: hash_loop_static<L, 7, HPC_LA>(D, bound, lane, S); break;
+            default: hash_loop_static<L, 9, HPC_LA>(D, bound, lane, S); break;
             }
         }
     } else {
