@@ -188,10 +188,31 @@ def main():
         n2 = orc.batch_count_timed(hb, hoff, args.l, args.k, args.density, omode, threads=ncpu)
         t2 = time.perf_counter() - t0
         assert n1 == n2
+        # the reference's own fast path is AVX-512 (HashMode::Simd / HpcSimd): time a restatement of it too, if the host can
+        avx = None
+        try:
+            av = so.OracleAvx512()
+            if av.supported():
+                hp = 1 if mode == pkg.HashMode.Hpc else 0
+                t0 = time.perf_counter()
+                a1 = av.batch_count(hb, hoff, args.l, args.k, args.density, hp, threads=1)
+                ta1 = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                a2 = av.batch_count(hb, hoff, args.l, args.k, args.density, hp, threads=ncpu)
+                ta2 = time.perf_counter() - t0
+                assert a1 == a2
+                avx = {"mode": "HpcSimd" if hp else "Simd", "value": round(ns * rl / ta1 / 1e9, 4), "cores": 1,
+                       "all_cores": {"value": round(ns * rl / ta2 / 1e9, 4), "cores": ncpu},
+                       "note": "oracle/s2k_oracle_avx512.c: restatement of the Simd-mode semantics (strict <, f32 bound), not the reference's code"}
+            else:
+                avx = "n/a (host CPU lacks AVX-512 F/BW/VL/VBMI2)"
+        except Exception as e:  # the baseline must never break the bench line
+            avx = "n/a (%s)" % type(e).__name__
         cpu = {"value": round(ns * rl / t1 / 1e9, 4), "unit": "Gbp/s", "cores": 1, "kind": "port",
                "sample": "first %d reads (%.2f Gbp) of the same synthetic workload, count-only iteration as in src/main.rs:65-76, "
                          "oracle/s2k_oracle.c built -O3 -march=native" % (ns, ns * rl / 1e9),
                "all_cores": {"value": round(ns * rl / t2 / 1e9, 4), "cores": ncpu},
+               "avx512": avx,
                "reference_published": "README.md:23: scalar ~0.1-0.2 GB/s, AVX-512 ~1 GB/s per thread (ntHash only, unstated CPU)"}
 
     if rank == 0:

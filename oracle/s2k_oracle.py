@@ -202,6 +202,67 @@ class Oracle:
         return out
 
 
+def build_avx512(out=None):
+    """Compile the AVX-512 CPU baseline (oracle/s2k_oracle_avx512.c) next to the scalar oracle.  Returns the path,
+    or None when the compiler rejects the flags."""
+    if out is None:
+        out = os.path.join(_HERE, "libs2k_oracle_avx512.so")
+    srcs = [os.path.join(_HERE, "s2k_oracle_avx512.c"), os.path.join(_HERE, "s2k_oracle.c")]
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(x) for x in srcs):
+        return out
+    tmpo = out + ".avx.o.%d" % os.getpid()
+    tmps = out + ".sc.o.%d" % os.getpid()
+    try:
+        subprocess.check_call(["gcc", "-O3", "-std=gnu11", "-fPIC", "-mavx512f", "-mavx512bw", "-mavx512vl", "-mavx512vbmi2",
+                               "-c", srcs[0], "-o", tmpo])
+        subprocess.check_call(["gcc", "-O3", "-std=c11", "-fPIC", "-c", srcs[1], "-o", tmps])
+        subprocess.check_call(["gcc", "-shared", "-pthread", "-o", out + ".tmp", tmpo, tmps, "-lm"])
+        os.replace(out + ".tmp", out)
+    except subprocess.CalledProcessError:
+        return None
+    finally:
+        for f in (tmpo, tmps):
+            if os.path.exists(f):
+                os.remove(f)
+    return out
+
+
+class OracleAvx512:
+    """AVX-512 restatement of the Simd / HpcSimd result semantics (CPU baseline; checked against Oracle)."""
+
+    def __init__(self):
+        path = build_avx512()
+        if path is None:
+            raise RuntimeError("cannot build the AVX-512 baseline with this compiler")
+        L = self.lib = C.CDLL(path)
+        L.s2k_avx512_supported.restype = C.c_int
+        L.s2k_avx512_minimizers.restype = C.c_size_t
+        L.s2k_avx512_minimizers.argtypes = [_u8p, C.c_size_t, C.c_uint, C.c_uint32, C.c_int, _u32p, _u32p, _u32p, C.c_size_t]
+        L.s2k_avx512_batch_count.restype = C.c_uint64
+        L.s2k_avx512_batch_count.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint64, C.c_uint, C.c_uint, C.c_double, C.c_int]
+        L.s2k_avx512_batch_count_mt.restype = C.c_uint64
+        L.s2k_avx512_batch_count_mt.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_double, C.c_int, C.c_int]
+
+    def supported(self):
+        return bool(self.lib.s2k_avx512_supported())
+
+    def minimizers(self, seq, l, bound, hpc):
+        s = Oracle._seq(seq)
+        n = self.lib.s2k_avx512_minimizers(_ptr(s, _u8p), len(s), l, bound, int(hpc), None, None, None, 0)
+        j = np.empty(n, dtype=np.uint32)
+        je = np.empty(n, dtype=np.uint32)
+        h = np.empty(n, dtype=np.uint32)
+        self.lib.s2k_avx512_minimizers(_ptr(s, _u8p), len(s), l, bound, int(hpc), _ptr(j, _u32p), _ptr(je, _u32p), _ptr(h, _u32p), n)
+        return j, je, h
+
+    def batch_count(self, bases, off, l, k, density, hpc, threads=1):
+        """total k-min-mers, count-only (src/main.rs:65-76 with HashMode::Simd/HpcSimd); pthreads over read shards"""
+        bases = Oracle._seq(bases)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        return int(self.lib.s2k_avx512_batch_count_mt(_ptr(bases, _u8p), _ptr(off, _u64p), len(off) - 1, l, k, density, int(hpc),
+                                                      int(threads)))
+
+
 _default = None
 
 
