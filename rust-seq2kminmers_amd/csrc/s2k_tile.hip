@@ -8,25 +8,38 @@
 //
 //  * The batch of reads is one byte stream; the stream is cut into fixed tiles of 64 x 144 = 9216
 //    bases, one wave per tile, independent of read lengths.  l-mers that straddle a read boundary
-//    are simply discarded when a hit is validated, so ragged reads cost nothing in the hot loop.
-//  * A tile is staged in LDS with coalesced 16 B/lane loads.  Each lane then owns 144 consecutive
-//    l-mer start positions and *rolls* the hash privately (fh' = rotl(fh,1) ^ OUT[s[p]] ^ IN[s[p+l]]),
-//    reading its bytes from LDS in 16 B pieces and its seeds from two 256-entry LDS tables that have
-//    the rotations pre-applied (one ds_read_b64 each).  The lane stride of 16*odd bytes makes the
-//    piece reads bank-conflict free.  A lane pays an l-base warm-up instead of a cross-lane scan.
-//  * Minimizers are rare (~2 % of positions), but a per-position branch is taken by almost every wave
-//    (64 lanes x 2 %).  So the hot loop is branch-free: it records a hit bit per position and keeps
-//    the hash of the last hit of each 8-position piece.  After the loop the wave turns the bitmasks
-//    into an ordered, dense list (prefix sums + select-nth-set-bit), validates every hit against the
-//    read table, back-maps positions and writes records; the rare second hit of a piece has its hash
-//    re-derived cooperatively by the whole wave.
+//    are cleared from the hit masks afterwards, so ragged reads cost nothing in the hot loop.
+//  * Persistent waves: a wave walks tiles t, t + n_waves, ...; the next tile's bytes (and the read-table
+//    entries of the next two tiles) are in flight into registers while the current tile is processed, so
+//    no global-load latency sits on the critical path after the first tile.
+//  * A tile is staged in LDS (1 KiB per wave-instruction).  Each lane then owns 144 consecutive l-mer
+//    start positions and *rolls* the hash privately (fh' = rotl(fh,1) ^ OUT[s[p]] ^ IN[s[p+l]]), reading
+//    its bytes from LDS in 16 B pieces (lane stride 16*odd bytes: bank-conflict free) and its seeds from
+//    two 256-entry LDS tables that have the rotations pre-applied (one ds_read_b64 each, one SDWA
+//    instruction per base for the address).  A lane pays an l-base warm-up instead of a cross-lane scan.
+//  * Minimizers are rare (~2 % of positions), but a per-position branch would be taken by almost every
+//    wave (64 lanes x 2 %).  So the hot loop is branch-free: per position it records a hit bit and keeps
+//    the hash of the last hit of each 8-position piece (compare -> select -> add-with-carry through VCC).
+//  * Dense phase: read starts become hash-space boundaries and invalid l-mers are cleared from the masks
+//    by range; popcounts + one DPP scan give every lane its output offset; lanes list their hits; then one
+//    lane per hit finds its read among the read starts kept in LDS, back-maps positions and writes the
+//    record with coalesced stores.  The ~7 % of hits that were not the last of their piece are queued and
+//    re-derived from their l bytes, one lane per hit.  No global LOAD sits in that loop: one would make
+//    the compiler drain every outstanding store of the previous round.
 //  * Hpc mode first compacts the tile's run heads in place in LDS (SWAR byte compares, per-lane
 //    popcounts, one wave scan, overwrite-style byte stores), appends the l run heads that follow the
-//    tile (a loop, so arbitrarily long homopolymers are fine), and then runs the same hash loop over
-//    the compacted bytes.  Raw positions are recovered for hits only, from the per-lane flag masks.
+//    tile (first from the staged look-ahead, then by a loop over the stream, so arbitrarily long
+//    homopolymers are fine), and then runs the same hash loop over the compacted bytes.  Raw positions
+//    are recovered for hits only, from the per-lane flag masks (owner-lane hint table + select-nth-bit).
 //    Read starts are forced run heads: they are marked with bit 7 of the staged byte, which is why
 //    Hpc tiles require 7-bit input (a byte >= 0x80 raises `non_ascii` and the host re-runs the call on
 //    the exact serial kernels).
+//  * Records go to a fixed per-tile slab (mean + 6 sigma); only a tile with more hits takes space from a
+//    shared overflow region with one atomic.  (One shared cursor for every tile serialised the kernel.)
+//
+// Diagnostics: S2K_DEBUG_SKIP (bit 1 skip hash loop, 2 skip dense phase, 4 skip compaction, 8 per-phase cycle
+// stamps printed by the host, 16/32/64 skip stores / per-read counts / re-derivation) and
+// S2K_DEBUG_BLOCKS_PER_CU are timing ablations only -- results are wrong when a skip bit is set.
 #include "s2k_dev.h"
 
 #include <cstdlib>
@@ -89,25 +102,6 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
     a += t;
     return a;
 }
-// XOR of v over the 64 lanes (returned in every lane): same DPP ladder as the scan, then lane 63's value
-__device__ inline uint32_t wave_xor(uint32_t v) {
-    uint32_t t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-    uint32_t a = v ^ t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-    a ^= t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);
-    a ^= t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x114, 0xf, 0xe, false);
-    a ^= t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x118, 0xf, 0xc, false);
-    a ^= t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x142, 0xa, 0xf, false);
-    a ^= t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, false);
-    a ^= t;
-    return (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
-}
 // value of lane `src` (wave-uniform index) in every lane: v_readlane, no LDS round trip
 __device__ inline uint32_t bcast(uint32_t v, int src) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
@@ -122,20 +116,6 @@ __device__ inline uint32_t select_nth_32(uint32_t w, uint32_t n) {
     c = __popc(w & 0x3u);    if (n >= c) { n -= c; r += 2;  w >>= 2; }
     c = w & 1u;              if (n >= c) { r += 1; }
     return r;
-}
-// n-th set bit over 5 words (160 bits)
-__device__ inline uint32_t select_nth_160(const uint32_t *w5, uint32_t n) {
-    uint32_t base = 0, word = w5[0];
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        uint32_t c = __popc(word);
-        if (n >= c && base == 32u * d) {
-            n -= c;
-            base += 32;
-            word = w5[d + 1];
-        }
-    }
-    return base + select_nth_32(word, n);
 }
 // bit i of a byte -> bit 4i
 __device__ inline uint32_t spread4(uint32_t x) {
@@ -158,7 +138,6 @@ __host__ __device__ constexpr uint32_t at_or_before(int d, int b) {
     return m;
 }
 
-__device__ inline uint32_t byte_of(const uint32_t *W, int idx) { return (W[idx >> 2] >> (8 * (idx & 3))) & 0xFFu; }
 // Seed look-ups of the hot loop.  The two 2 KiB tables sit at LDS byte offsets 0 (IN pairs) and 2048 (OUT
 // pairs); the kernel has no static LDS, so the dynamic region starts at 0 (checked at kernel entry).  The byte
 // offset of a base's entries is formed ONCE, when the base enters the window, by one v_lshlrev_b32_sdwa (byte
