@@ -564,6 +564,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
     if (lane == 0) S.rs[0] = rs0;
     {
         uint64_t bpos = bpos0; // read_off[r0 + 1 + lane], fetched ahead; later chunks are loaded here (rare)
+        uint64_t chunk_prev = rs0; // start of the read whose end lane 0 holds
         for (uint32_t c0 = 0;; c0 += 64) { // wave-uniform; one trip unless the tile holds > 63 read starts
             const bool internal = bpos > t0 && bpos < tile_end;
             const bool external = bpos >= tile_end; // entry n_reads (end of stream) always qualifies
@@ -617,6 +618,28 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                         }
                     }
                 }
+            }
+            if constexpr (!HPC) {
+                // A read of exactly l bases has one l-mer that fits, but the reference yields nothing unless
+                // seq.len() > l (src/lib.rs:97): clear that position.  Lane i holds the END of read r0+c0+i
+                // (= start of the next one); its start is the previous lane's value (rs0 / the previous chunk's
+                // last value for lane 0).
+                uint64_t pstart = ((uint64_t)__shfl_up((uint32_t)(bpos >> 32), 1) << 32) | __shfl_up((uint32_t)bpos, 1);
+                if (lane == 0) pstart = chunk_prev;
+                const bool exact = bpos != ~0ull && bpos - pstart == (uint64_t)l && pstart >= t0 && pstart < tile_end;
+                uint64_t ex = __ballot(exact);
+                while (ex) {
+                    const int z = __builtin_ctzll(ex);
+                    ex &= ex - 1;
+                    const uint32_t hx = bcast((uint32_t)(pstart - t0), z); // tile-local position of that read's only l-mer
+                    const int rel = (int)hx - (int)(Tq * lane);
+                    if (rel >= 0 && rel < (int)Tq) {
+#pragma unroll
+                        for (int d = 0; d < 5; d++) // static indices: vm[] must stay in registers
+                            if ((rel >> 5) == d) vm[d] &= ~(1u << (rel & 31));
+                    }
+                }
+                chunk_prev = ((uint64_t)bcast((uint32_t)(bpos >> 32), 63) << 32) | bcast((uint32_t)bpos, 63);
             }
             if (!many && internal && c0 + lane < 63) { // remembered for the per-hit read lookup
                 S.hb[c0 + lane] = HB;
@@ -1025,19 +1048,23 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
                            uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts) {
     auto kern = tile_minimizer_kernel<L, HPC>;
     const int lds = block_lds_bytes<HPC>();
-    static int n_cu = 0, per_cu = 0; // per instantiation
-    if (n_cu == 0) {
+    // per instantiation AND per device: function attributes and occupancy belong to the device the module is loaded on
+    constexpr int MAX_DEV = 64;
+    static int n_cu_d[MAX_DEV] = {0}, per_cu_d[MAX_DEV] = {0};
+    int dev = 0;
+    S2K_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEV) return hipErrorInvalidDevice;
+    if (n_cu_d[dev] == 0) {
         S2K_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        int dev = 0;
-        S2K_HIP_CHECK(hipGetDevice(&dev));
         hipDeviceProp_t prop;
         S2K_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         int occ = 0;
         S2K_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64 * TW, lds));
-        per_cu = occ < 1 ? 1 : occ;
-        if (const char *e = getenv("S2K_DEBUG_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu; // occupancy experiments
-        n_cu = prop.multiProcessorCount;
+        per_cu_d[dev] = occ < 1 ? 1 : occ;
+        if (const char *e = getenv("S2K_DEBUG_BLOCKS_PER_CU")) per_cu_d[dev] = atoi(e) > 0 ? atoi(e) : per_cu_d[dev]; // occupancy experiments
+        n_cu_d[dev] = prop.multiProcessorCount;
     }
+    const int n_cu = n_cu_d[dev], per_cu = per_cu_d[dev];
     uint64_t blocks = (n_tiles + TW - 1) / TW;
     const uint64_t resident = (uint64_t)n_cu * per_cu;
     if (blocks > resident) blocks = resident; // persistent: waves loop over the remaining tiles

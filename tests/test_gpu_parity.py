@@ -311,3 +311,13 @@ def test_baseline_config5_mbp_contigs_sparse_density(eng, oracle):
     for mode in SCALAR:
         got = compare(eng, oracle, reads, 31, 10, 0.001, mode, expect_path=0, tag="C5-contigs")
         assert got["counts"]["hash_bound"] == 4294967
+
+
+def test_degenerate_batches(eng, oracle):
+    """no reads at all; only empty reads; a single base; everything shorter than l"""
+    for mode in SCALAR + (HM.Simd, HM.HpcSimd):
+        r = eng.extract(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64), 31, 10, 0.01, mode, want_minimizers=True)
+        assert r["n"] == 0 and r["n_minimizers"] == 0 and list(r["km_off"]) == [0]
+        compare(eng, oracle, [b"", b"", b""], 31, 10, 0.01, mode, tag="all-empty")
+        compare(eng, oracle, [b"A"], 31, 10, 0.5, mode, tag="one-base")
+        compare(eng, oracle, [b"ACGT" * 7, b"", b"ACGTTGCA" * 3 + b"ACGTTGC"], 31, 1, 1.0, mode, tag="shorter-than-l")
