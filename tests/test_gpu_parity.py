@@ -321,3 +321,33 @@ def test_degenerate_batches(eng, oracle):
         compare(eng, oracle, [b"", b"", b""], 31, 10, 0.01, mode, tag="all-empty")
         compare(eng, oracle, [b"A"], 31, 10, 0.5, mode, tag="one-base")
         compare(eng, oracle, [b"ACGT" * 7, b"", b"ACGTTGCA" * 3 + b"ACGTTGC"], 31, 1, 1.0, mode, tag="shorter-than-l")
+
+
+def test_fuzz_random_batches(eng, oracle):
+    """Randomised batches: read lengths clustered around l, around the 144-base lane chunks and around the 9216-base
+    tiles, mixed with long reads; random l (static and dynamic instantiations), k, density, alphabet noise."""
+    rng = np.random.default_rng(2026)
+    T = 9216
+    for it in range(40):
+        l = int(rng.choice([31, 31, 31, 5, 12, 16, 20, 31, 32, 40, 64]))
+        k = int(rng.choice([1, 2, 3, 5, 10, 17]))
+        d = float(rng.choice([0.003, 0.01, 0.02, 0.1, 0.5]))
+        n_reads = int(rng.integers(1, 60))
+        lens = []
+        for _ in range(n_reads):
+            kind = rng.integers(0, 6)
+            if kind == 0:
+                lens.append(int(max(0, l + rng.integers(-3, 4))))
+            elif kind == 1:
+                lens.append(int(144 * rng.integers(1, 5) + rng.integers(-2, 3)))
+            elif kind == 2:
+                lens.append(int(T * rng.integers(1, 3) + rng.integers(-40, 41)))
+            elif kind == 3:
+                lens.append(int(rng.integers(0, 400)))
+            else:
+                lens.append(int(rng.integers(1000, 30000)))
+        hp = float(rng.choice([0.0, 0.2, 0.5]))
+        odd = float(rng.choice([0.0, 0.0, 0.03]))
+        reads = [rand_read(rng, n, hp=hp, odd=odd) for n in lens]
+        for mode in SCALAR:
+            compare(eng, oracle, reads, l, k, d, mode, expect_path=0, tag="fuzz%d" % it)
