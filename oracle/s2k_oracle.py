@@ -41,7 +41,18 @@ def _ptr(a, t):
 class Oracle:
     def __init__(self, path=None, native=False):
         if path is None:
-            path = build(native=native, out=os.path.join(_HERE, "libs2k_oracle_native.so") if native else None)
+            out = None
+            if native:  # -march=native objects must never travel between hosts: key the file by the CPU model
+                import hashlib
+
+                model = ""
+                try:
+                    with open("/proc/cpuinfo") as f:
+                        model = next((ln for ln in f if ln.startswith("model name")), "")
+                except OSError:
+                    pass
+                out = os.path.join(_HERE, "libs2k_oracle_native_%s.so" % hashlib.md5(model.encode()).hexdigest()[:8])
+            path = build(native=native, out=out)
         L = self.lib = C.CDLL(path)
         L.s2k_oracle_hash_bound.restype = C.c_uint32
         L.s2k_oracle_hash_bound.argtypes = [C.c_double]
