@@ -9,8 +9,9 @@
 // Input: minimizer records grouped in "tiles" (a stream tile of the tiled kernel, or a whole read for
 // the serial kernels).  Tiles are in stream order and records inside a tile are in position order, so
 // the concatenation of tiles is the global minimizer sequence sorted by (read, position); tile_goff is
-// its exclusive prefix.  One wave per tile; 64 records per round; the round's mixed hashes plus the
-// k-1 records that follow (possibly in later tiles) are staged in LDS.
+// its exclusive prefix.  One wave per tile.  Two kernels: `kminmer_kernel_fast` (k <= 65, the normal case: 128
+// records per pass, three global round trips per tile) and `kminmer_kernel` (any k up to 4096; k > 65 walks the
+// following tiles per window instead of staging them in LDS).
 #include "s2k_dev.h"
 
 namespace s2k {
