@@ -351,3 +351,56 @@ def test_fuzz_random_batches(eng, oracle):
         reads = [rand_read(rng, n, hp=hp, odd=odd) for n in lens]
         for mode in SCALAR:
             compare(eng, oracle, reads, l, k, d, mode, expect_path=0, tag="fuzz%d" % it)
+
+
+def test_device_api_streams_timing_and_minimizer_capacity(eng, oracle):
+    """s2k_set_stream with a non-default torch stream, HIP-event timing totals, minimizer-triple capacity."""
+    import torch
+
+    rng = np.random.default_rng(14)
+    reads = [rand_read(rng, 12000, hp=0.1) for _ in range(40)]
+    bases, off = pkg.pack_reads(reads)
+    dev = torch.device("cuda", 0)
+    d_b = torch.from_numpy(bases).to(dev)
+    d_o = torch.from_numpy(off.astype(np.int64)).to(dev)
+    ref = oracle.batch(bases, off, 31, 10, 0.01, 1)
+    rm = oracle.batch_minimizers(bases, off, 31, 0.01, 1)
+    nk, nm = ref["n"], rm["n"]
+
+    def mk(kcap, mcap):
+        t = {n: torch.zeros(max(c, 1), dtype=dt, device=dev) for n, c, dt in (
+            ("hash", kcap, torch.int64), ("start", kcap, torch.int32), ("end", kcap, torch.int32), ("rev", kcap, torch.uint8),
+            ("mn_j", mcap, torch.int32), ("mn_jend", mcap, torch.int32), ("mn_hash", mcap, torch.int32))}
+        t["km_off"] = torch.zeros(len(reads) + 1, dtype=torch.int64, device=dev)
+        t["mn_off"] = torch.zeros(len(reads) + 1, dtype=torch.int64, device=dev)
+        o = pkg.DeviceOut()
+        o.km_capacity, o.mn_capacity = kcap, mcap
+        for f in ("km_off", "hash", "start", "end", "rev", "mn_off", "mn_j", "mn_jend", "mn_hash"):
+            setattr(o, f, t[f].data_ptr())
+        return t, o
+
+    e2 = pkg.Engine(0)
+    side = torch.cuda.Stream(device=dev)
+    e2.set_stream(side.cuda_stream)
+    torch.cuda.synchronize()
+    e2.enable_timing(True)
+    t, o = mk(nk, nm)
+    for _ in range(3):
+        e2.extract_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), len(bases), 31, 10, 0.01, 1, o, sync=False)
+    c = e2.sync()
+    ms_all, n_calls = e2.timing_total(0)
+    ms_min, _ = e2.timing_total(1)
+    assert n_calls == 3 and 0 < ms_min <= ms_all and e2.last_kernel_ms(1) > 0
+    assert c["n_kminmers"] == nk and c["n_minimizers"] == nm
+    side.synchronize()
+    assert (t["hash"].cpu().numpy().view(np.uint64) == ref["hash"]).all()
+    assert (t["mn_j"].cpu().numpy().view(np.uint32) == rm["j"]).all() and (t["mn_hash"].cpu().numpy().view(np.uint32) == rm["hash"]).all()
+    assert (t["mn_off"].cpu().numpy().view(np.uint64) == rm["mn_off"]).all()
+    # minimizer arrays too small -> S2K_ERR_CAPACITY, k-min-mer outputs still complete and correct
+    t, o = mk(nk, nm // 3)
+    with pytest.raises(pkg.S2kError) as e:
+        e2.extract_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), len(bases), 31, 10, 0.01, 1, o)
+    assert e.value.status == 7
+    assert (t["hash"].cpu().numpy().view(np.uint64) == ref["hash"]).all()
+    assert (t["mn_j"].cpu().numpy().view(np.uint32)[: nm // 3] == rm["j"][: nm // 3]).all()
+    e2.close()
