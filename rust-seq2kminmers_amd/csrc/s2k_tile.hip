@@ -390,6 +390,16 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
 #pragma unroll
     for (int g = 0; g < 5; g++) S.fm[lane][g] = fmk[g];
     S.hbase[lane] = base;
+    { // hint table for the back-map: hl[q] = raw lane that owns run head Tq*q (first head of hash lane q).  Raw lane
+      // o owns heads [base, base+cnt), i.e. the hash-lane starts q with base <= Tq*q < base+cnt: at most a few.
+        const uint32_t need = (R + 1023u) >> 10;
+        const uint32_t tq = 16u * (need <= 1 ? 1u : need <= 3 ? 3u : need <= 5 ? 5u : need <= 7 ? 7u : 9u);
+        S.hl[lane] = 63; // hash lanes past the last head
+        wave_sync();
+        if (cnt) {
+            for (uint32_t q = (base + tq - 1) / tq; q * tq < base + cnt && q < 64; q++) S.hl[q] = (uint8_t)lane;
+        }
+    }
     // all lanes hold their raw chunk in registers now -> the buffer may be overwritten in place
     wave_sync();
     S2K_STAMP(14); // compaction: chunk load + flags + scan
@@ -536,18 +546,6 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
     //     end of the stream) is the one external boundary.
     const uint32_t wclr = HPC ? l : l - 1;
     const uint32_t rcpTq = 0xFFFFFFFFu / Tq + 1u; // x / Tq == umulhi(x, rcpTq) for x < 2^16 (Tq <= 144)
-    if constexpr (HPC) { // hint table for the back-map: owner raw lane of the first run head of every hash lane
-        const uint32_t xq = Tq * (uint32_t)lane;
-        uint32_t o = 0;
-        if (xq < nh) {
-#pragma unroll
-            for (int step = 32; step; step >>= 1)
-                if (S.hbase[o + step] <= xq) o += step;
-        } else {
-            o = 63;
-        }
-        S.hl[lane] = (uint8_t)o;
-    }
     uint32_t vm[5]; // validated hit mask of this lane
     {
         int vc = (int)nh - (int)(Tq * lane); // hash positions of this lane that exist
