@@ -751,6 +751,73 @@ uint64_t s2k_oracle_batch(const uint8_t *bases, const uint64_t *off, uint64_t n_
     return total;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Whole-run checksums of a synthetic batch (n_reads reads of read_len bases cut from the synth_bases stream
+ * of `seed`), generated read by read so that BASELINE-size runs (10 Gbp) need no 10 GB host buffer.
+ * out = { n_minimizers, n_kminmers, XOR hash, SUM start, SUM end, #rev }.
+ * ---------------------------------------------------------------------------------------- */
+struct sum_job {
+    uint64_t seed, r0, r1, read_len;
+    unsigned l, k;
+    uint32_t bound;
+    int mode;
+    uint64_t out[6];
+};
+
+static void *sum_worker(void *p) {
+    struct sum_job *jb = (struct sum_job *)p;
+    uint8_t *buf = (uint8_t *)malloc(jb->read_len + 1);
+    size_t ocap = jb->read_len + 1, scap = 0;
+    uint64_t *h = (uint64_t *)malloc(ocap * 8), *st = (uint64_t *)malloc(ocap * 8), *en = (uint64_t *)malloc(ocap * 8);
+    uint8_t *rv = (uint8_t *)malloc(ocap);
+    uint64_t *scratch = NULL;
+    for (uint64_t r = jb->r0; r < jb->r1; r++) {
+        s2k_oracle_synth_bases(jb->seed, r * jb->read_len, jb->read_len, buf);
+        size_t M = s2k_oracle_minimizers(buf, jb->read_len, jb->l, jb->bound, jb->mode, NULL, NULL, NULL, 0);
+        size_t c = kminmers_one(buf, jb->read_len, jb->l, jb->k, jb->bound, jb->mode, h, st, en, rv, ocap, &scratch, &scap);
+        jb->out[0] += M;
+        jb->out[1] += c;
+        for (size_t i = 0; i < c; i++) {
+            jb->out[2] ^= h[i];
+            jb->out[3] += st[i];
+            jb->out[4] += en[i];
+            jb->out[5] += rv[i];
+        }
+    }
+    free(buf); free(h); free(st); free(en); free(rv); free(scratch);
+    return NULL;
+}
+
+void s2k_oracle_synth_checksums(uint64_t seed, uint64_t n_reads, uint64_t read_len, unsigned l, unsigned k,
+                                double density, int mode, int threads, uint64_t out[6]) {
+    tables();
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > n_reads) threads = n_reads ? (int)n_reads : 1;
+    struct sum_job *jobs = (struct sum_job *)calloc(threads, sizeof(*jobs));
+    pthread_t *th = (pthread_t *)malloc(sizeof(*th) * threads);
+    for (int t = 0; t < threads; t++) {
+        jobs[t].seed = seed;
+        jobs[t].r0 = n_reads * (uint64_t)t / threads;
+        jobs[t].r1 = n_reads * (uint64_t)(t + 1) / threads;
+        jobs[t].read_len = read_len;
+        jobs[t].l = l;
+        jobs[t].k = k;
+        jobs[t].bound = s2k_oracle_hash_bound(density);
+        jobs[t].mode = mode;
+        pthread_create(&th[t], NULL, sum_worker, &jobs[t]);
+    }
+    memset(out, 0, 6 * sizeof(uint64_t));
+    for (int t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        out[0] += jobs[t].out[0];
+        out[1] += jobs[t].out[1];
+        out[2] ^= jobs[t].out[2];
+        for (int i = 3; i < 6; i++) out[i] += jobs[t].out[i];
+    }
+    free(jobs);
+    free(th);
+}
+
 uint64_t s2k_oracle_batch_minimizers(const uint8_t *bases, const uint64_t *off, uint64_t n_reads, unsigned l,
                                      double density, int mode, uint64_t *mn_off, uint32_t *j, uint32_t *jend,
                                      uint32_t *hash, uint64_t cap) {

@@ -99,6 +99,11 @@ uint64_t s2k_oracle_batch_minimizers(const uint8_t *bases, const uint64_t *off, 
  * the device generator in the product library so inputs can be created in HBM. */
 void s2k_oracle_synth_bases(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *out);
 
+/* Whole-run checksums of n_reads synthetic reads of read_len bases (read r = synth stream [r*read_len, (r+1)*read_len)),
+ * generated on the fly: out = { n_minimizers, n_kminmers, XOR hash, SUM start, SUM end, #rev }. */
+void s2k_oracle_synth_checksums(uint64_t seed, uint64_t n_reads, uint64_t read_len, unsigned l, unsigned k,
+                                double density, int mode, int threads, uint64_t out[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,9 @@ class Oracle:
                                                   _u64p, _u32p, _u32p, _u32p, C.c_uint64]
         L.s2k_oracle_synth_bases.restype = None
         L.s2k_oracle_synth_bases.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u8p]
+        L.s2k_oracle_synth_checksums.restype = None
+        L.s2k_oracle_synth_checksums.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_uint, C.c_double,
+                                                 C.c_int, C.c_int, _u64p]
 
     # -- scalars ---------------------------------------------------------------------------
     def hash_bound(self, d):
@@ -192,6 +195,12 @@ class Oracle:
         off = np.ascontiguousarray(off, dtype=np.uint64)
         return int(self.lib.s2k_oracle_batch(_ptr(bases, _u8p), _ptr(off, _u64p), len(off) - 1, l, k, density, mode,
                                              threads, None, None, None, None, None, 0))
+
+    def synth_checksums(self, seed, n_reads, read_len, l, k, density, mode, threads=1):
+        """whole-run checksums of a synthetic batch generated read by read (no big host buffer)"""
+        out = np.zeros(6, dtype=np.uint64)
+        self.lib.s2k_oracle_synth_checksums(seed, n_reads, read_len, l, k, density, mode, threads, _ptr(out, _u64p))
+        return dict(zip(("n_minimizers", "n_kminmers", "xor_hash", "sum_start", "sum_end", "n_rev"), map(int, out)))
 
     def batch_minimizers(self, bases, off, l, density, mode):
         bases = self._seq(bases)

@@ -268,6 +268,51 @@ def test_synthetic_config2_sample_properties(eng, oracle):
             assert (a["end"][s:e] > a["start"][s:e]).all() and int(a["end"][s:e].max(initial=0)) < L
 
 
+def _xor_reduce(t):
+    import torch
+
+    while t.numel() > 1:
+        h = t.numel() // 2
+        r = t[:h] ^ t[h:2 * h]
+        t = torch.cat((r, t[2 * h:])) if t.numel() & 1 else r
+    return int(t.item()) & 0xFFFFFFFFFFFFFFFF if t.numel() else 0
+
+
+def test_full_size_config2_whole_run_checksums(eng, oracle):
+    """BASELINE config 2 at its full size -- 1 000 000 x 10 kbp = 10 Gbp, l=31 k=10 d=0.01, both scalar modes:
+    every k-min-mer the GPU wrote is folded into count / XOR(hash) / SUM(start) / SUM(end) / #rev and compared with
+    the oracle run over the same 10 Gbp on the host cores (reads generated on the fly on both sides)."""
+    import os
+    import torch
+
+    n_reads, L, seed = 1_000_000, 10_000, 1
+    dev = torch.device("cuda", 0)
+    d_b = torch.empty(n_reads * L + 64, dtype=torch.uint8, device=dev)
+    d_o = (torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L)
+    torch.cuda.synchronize()
+    eng.synth_bases_device(seed, 0, n_reads * L, d_b.data_ptr())
+    cap = int(n_reads * L * 0.0215)
+    t = {"km_off": torch.empty(n_reads + 1, dtype=torch.int64, device=dev), "hash": torch.empty(cap, dtype=torch.int64, device=dev),
+         "start": torch.empty(cap, dtype=torch.int32, device=dev), "end": torch.empty(cap, dtype=torch.int32, device=dev),
+         "rev": torch.empty(cap, dtype=torch.uint8, device=dev)}
+    o = pkg.DeviceOut()
+    o.km_capacity = cap
+    o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    for mode in SCALAR:
+        torch.cuda.synchronize()
+        c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_reads * L, 31, 10, 0.01, int(mode), o)
+        ref = oracle.synth_checksums(seed, n_reads, L, 31, 10, 0.01, OMODE[mode], threads=threads)
+        n = c["n_kminmers"]
+        assert c["path"] == 0 and c["n_bases"] == n_reads * L
+        assert (n, c["n_minimizers"], c["xor_hash"]) == (ref["n_kminmers"], ref["n_minimizers"], ref["xor_hash"]), (int(mode), c, ref)
+        assert int(t["km_off"][-1].item()) == n and bool((t["km_off"][1:] >= t["km_off"][:-1]).all())
+        assert _xor_reduce(t["hash"][:n]) == ref["xor_hash"]
+        assert int(t["start"][:n].to(torch.int64).sum().item()) == ref["sum_start"]
+        assert int(t["end"][:n].to(torch.int64).sum().item()) == ref["sum_end"]
+        assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"]
+
+
 def _lognormal_lengths(rng, n, mean, sigma, lo, hi):
     mu = np.log(mean) - sigma * sigma / 2
     return np.clip(rng.lognormal(mu, sigma, size=n), lo, hi).astype(np.int64)

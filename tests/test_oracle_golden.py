@@ -218,3 +218,19 @@ def test_synth_is_position_keyed(oracle):
     assert set(a.tobytes()) <= set(b"ACGT")
     cnt = np.bincount(oracle.synth_bases(9, 0, 200000), minlength=256)
     assert all(abs(cnt[c] - 50000) < 1500 for c in b"ACGT")
+
+
+def test_synth_checksums_equal_materialised_batch(oracle):
+    """the read-by-read checksum driver used by the full-size GPU parity test agrees with the batch API"""
+    n_reads, L = 37, 3001
+    bases = oracle.synth_bases(5, 0, n_reads * L)
+    off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    for mode in (0, 1):
+        ref = oracle.batch(bases, off, 31, 10, 0.01, mode, threads=2)
+        cs = oracle.synth_checksums(5, n_reads, L, 31, 10, 0.01, mode, threads=3)
+        assert cs["n_kminmers"] == ref["n"] > 0
+        assert cs["xor_hash"] == int(np.bitwise_xor.reduce(ref["hash"]))
+        assert cs["sum_start"] == int(ref["start"].astype(np.uint64).sum())
+        assert cs["sum_end"] == int(ref["end"].astype(np.uint64).sum())
+        assert cs["n_rev"] == int(ref["rev"].sum())
+        assert cs["n_minimizers"] == int(oracle.batch_minimizers(bases, off, 31, 0.01, mode)["n"])
