@@ -3,6 +3,7 @@
 // s2k_create() fails with S2K_ERR_NO_DEVICE.
 #include "../../include/s2k.h"
 #include "s2k_dev.h"
+#include "s2k_hostcopy.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -17,10 +18,15 @@ static_assert(offsetof(Counts, path) == offsetof(s2k_counts, path), "Counts must
 
 namespace {
 
-struct HostOwner { // backing store of an s2k_result
-    std::vector<uint64_t> km_off, hash, mn_off;
-    std::vector<uint32_t> start, end, mn_j, mn_jend, mn_hash;
-    std::vector<uint8_t> rev;
+struct HostOwner { // backing store of an s2k_result: plain malloc (no zero fill -- the arrays are overwritten whole)
+    void *p[9] = {};
+    template <typename T> T *take(int slot, uint64_t n) {
+        p[slot] = malloc((n ? n : 1) * sizeof(T));
+        return (T *)p[slot];
+    }
+    ~HostOwner() {
+        for (void *q : p) free(q);
+    }
 };
 
 struct DevBuf {
@@ -89,6 +95,7 @@ struct s2k_ctx {
     bool pending = false;
     s2k_status pending_status = S2K_OK;
     std::string err;
+    s2k::HostStager stager; // pinned ring + copy threads of the host-buffer entry points
 };
 
 namespace {
@@ -530,7 +537,7 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
     S2K_TRY(ctx->in_off.ensure((n_reads + 1) * sizeof(uint64_t)), "input allocation");
     std::vector<uint64_t> off(n_reads + 1);
     for (uint64_t r = 0; r <= n_reads; r++) off[r] = read_off[r] - first;
-    if (n_bases) S2K_TRY(hipMemcpyAsync(ctx->in_bases.p, bases + first, n_bases, hipMemcpyHostToDevice, ctx->stream), "H2D bases");
+    S2K_TRY(ctx->stager.h2d(ctx->in_bases.p, bases + first, n_bases, ctx->stream), "H2D bases");
     S2K_TRY(hipMemcpyAsync(ctx->in_off.p, off.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream), "H2D offsets");
     S2K_TRY(hipStreamSynchronize(ctx->stream), "H2D sync");
 
@@ -577,46 +584,46 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
     HostOwner *ow = new (std::nothrow) HostOwner();
     if (!ow) return fail(ctx, S2K_ERR_NOMEM, "host result allocation");
     const uint64_t nk = cnt.n_kminmers, nm = cnt.n_minimizers;
-    ow->km_off.resize(n_reads + 1);
-    ow->hash.resize(nk);
-    ow->start.resize(nk);
-    ow->end.resize(nk);
-    ow->rev.resize(nk);
+    res->km_off = ow->take<uint64_t>(0, n_reads + 1);
+    res->hash = ow->take<uint64_t>(1, nk);
+    res->start = ow->take<uint32_t>(2, nk);
+    res->end = ow->take<uint32_t>(3, nk);
+    res->rev = ow->take<uint8_t>(4, nk);
+    if (want_mn) {
+        res->mn_off = ow->take<uint64_t>(5, n_reads + 1);
+        res->mn_j = ow->take<uint32_t>(6, nm);
+        res->mn_jend = ow->take<uint32_t>(7, nm);
+        res->mn_hash = ow->take<uint32_t>(8, nm);
+    }
+    bool mem_ok = true;
+    for (int i = 0; i < (want_mn ? 9 : 5); i++) mem_ok = mem_ok && ow->p[i];
+    if (!mem_ok) {
+        delete ow;
+        memset(res, 0, sizeof *res);
+        return fail(ctx, S2K_ERR_NOMEM, "host result allocation");
+    }
     hipStream_t s = ctx->stream;
-    hipError_t e = hipMemcpyAsync(ow->km_off.data(), o.km_off, (n_reads + 1) * 8, hipMemcpyDeviceToHost, s);
-    if (nk && e == hipSuccess) e = hipMemcpyAsync(ow->hash.data(), o.hash, nk * 8, hipMemcpyDeviceToHost, s);
-    if (nk && e == hipSuccess) e = hipMemcpyAsync(ow->start.data(), o.start, nk * 4, hipMemcpyDeviceToHost, s);
-    if (nk && e == hipSuccess) e = hipMemcpyAsync(ow->end.data(), o.end, nk * 4, hipMemcpyDeviceToHost, s);
-    if (nk && e == hipSuccess) e = hipMemcpyAsync(ow->rev.data(), o.rev, nk, hipMemcpyDeviceToHost, s);
-    if (want_mn && e == hipSuccess) {
-        ow->mn_off.resize(n_reads + 1);
-        ow->mn_j.resize(nm);
-        ow->mn_jend.resize(nm);
-        ow->mn_hash.resize(nm);
-        e = hipMemcpyAsync(ow->mn_off.data(), o.mn_off, (n_reads + 1) * 8, hipMemcpyDeviceToHost, s);
-        if (nm && e == hipSuccess) e = hipMemcpyAsync(ow->mn_j.data(), o.mn_j, nm * 4, hipMemcpyDeviceToHost, s);
-        if (nm && e == hipSuccess) e = hipMemcpyAsync(ow->mn_jend.data(), o.mn_jend, nm * 4, hipMemcpyDeviceToHost, s);
-        if (nm && e == hipSuccess) e = hipMemcpyAsync(ow->mn_hash.data(), o.mn_hash, nm * 4, hipMemcpyDeviceToHost, s);
+    s2k::HostStager &hs = ctx->stager;
+    hipError_t e = hs.d2h(res->km_off, o.km_off, (n_reads + 1) * 8, s);
+    if (e == hipSuccess) e = hs.d2h(res->hash, o.hash, nk * 8, s);
+    if (e == hipSuccess) e = hs.d2h(res->start, o.start, nk * 4, s);
+    if (e == hipSuccess) e = hs.d2h(res->end, o.end, nk * 4, s);
+    if (e == hipSuccess) e = hs.d2h(res->rev, o.rev, nk, s);
+    if (want_mn) {
+        if (e == hipSuccess) e = hs.d2h(res->mn_off, o.mn_off, (n_reads + 1) * 8, s);
+        if (e == hipSuccess) e = hs.d2h(res->mn_j, o.mn_j, nm * 4, s);
+        if (e == hipSuccess) e = hs.d2h(res->mn_jend, o.mn_jend, nm * 4, s);
+        if (e == hipSuccess) e = hs.d2h(res->mn_hash, o.mn_hash, nm * 4, s);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         delete ow;
+        memset(res, 0, sizeof *res);
         return fail(ctx, S2K_ERR_DEVICE, "D2H results", e);
     }
     res->n_reads = n_reads;
     res->n_kminmers = nk;
-    res->km_off = ow->km_off.data();
-    res->hash = ow->hash.data();
-    res->start = ow->start.data();
-    res->end = ow->end.data();
-    res->rev = ow->rev.data();
-    if (want_mn) {
-        res->n_minimizers = nm;
-        res->mn_off = ow->mn_off.data();
-        res->mn_j = ow->mn_j.data();
-        res->mn_jend = ow->mn_jend.data();
-        res->mn_hash = ow->mn_hash.data();
-    }
+    res->n_minimizers = want_mn ? nm : 0;
     res->counts = cnt;
     res->_owner = ow;
     return S2K_OK;

@@ -1,0 +1,64 @@
+// Host <-> HBM transfers for the host-buffer entry points (s2k_extract, the FASTX pipeline).
+//
+// The reference's boundary hands over pageable `&[u8]` slices (src/lib.rs:89); a plain hipMemcpy from pageable
+// memory is bounced through the runtime's own small staging buffers on one thread and reaches only a fraction of
+// the PCIe rate.  HostStager keeps a ring of pinned chunks and a few copy threads: while the DMA engine moves
+// chunk i, the threads fill (or drain) chunk i+1, so a transfer runs at min(memcpy rate of the pool, PCIe).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace s2k {
+
+class CopyPool { // fixed set of threads that split one memcpy between them
+public:
+    explicit CopyPool(int threads);
+    ~CopyPool();
+    void copy(void *dst, const void *src, size_t bytes); // returns when done
+    int threads() const { return (int)workers_.size() + 1; }
+
+private:
+    void worker(int idx);
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    uint64_t gen_ = 0;
+    int remaining_ = 0;
+    bool stop_ = false;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+class HostStager {
+public:
+    HostStager() = default;
+    ~HostStager();
+    HostStager(const HostStager &) = delete;
+    HostStager &operator=(const HostStager &) = delete;
+    // pageable host -> device.  On return every byte of `src` has been read (the caller may reuse it) and the last
+    // DMA is queued on `s`; work queued on `s` afterwards sees the data.
+    hipError_t h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);
+    // device -> pageable host, ordered after the work already queued on `s`.  On return `dst` is complete.
+    hipError_t d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
+
+    static constexpr size_t kChunk = 32u << 20;
+    static constexpr int kSlots = 3;
+    static constexpr size_t kSmall = 1u << 20; // below this the runtime's own path is as good
+
+private:
+    hipError_t init();
+    bool ready_ = false;
+    char *pin_[kSlots] = {};
+    hipEvent_t ev_[kSlots] = {};
+    CopyPool *pool_ = nullptr;
+};
+
+} // namespace s2k
