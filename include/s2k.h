@@ -175,8 +175,18 @@ s2k_fastx *s2k_fastx_open(const char *path, s2k_status *status);
 s2k_status s2k_fastx_next(s2k_fastx *rd, uint64_t max_bases, uint64_t max_reads, const uint8_t **bases,
                           const uint64_t **read_off, uint64_t *n_reads);
 void s2k_fastx_close(s2k_fastx *rd);
-/* Streams a whole file through the GPU in batches of ~batch_bases (parsing batch i+1 overlaps the kernels of
- * batch i) and returns the totals; k-min-mers are produced in HBM and counted, like the reference's demo task
+/* Record splitting on the GPU: FASTA/FASTQ text that is already in HBM (d_text, 16-byte aligned, < 4 GiB, beginning
+ * at a record start and ending at a record end) becomes the (bases, read_off) pair s2k_extract_device consumes.
+ * format: S2K_FASTA (multi-line allowed) or S2K_FASTQ (strict 4-line records).  *n_reads / *n_bases always receive
+ * the sizes; S2K_ERR_CAPACITY when bases_capacity < *n_bases or off_capacity < *n_reads + 1 (call again),
+ * S2K_ERR_INVALID_ARG for malformed text. */
+enum { S2K_FASTA = 0, S2K_FASTQ = 1 };
+s2k_status s2k_fastx_parse_device(s2k_ctx *ctx, const uint8_t *d_text, uint64_t n_bytes, int format, uint8_t *d_bases,
+                                  uint64_t bases_capacity, uint64_t *d_read_off, uint64_t off_capacity,
+                                  uint64_t *n_reads, uint64_t *n_bases);
+/* Streams a whole file through the GPU in batches of ~batch_bases and returns the totals: the file's bytes are
+ * staged to HBM by several threads, records are split on the GPU (as s2k_fastx_parse_device), and staging +
+ * splitting of batch i+1 overlap the k-min-mer kernels of batch i; k-min-mers are produced in HBM and counted, like the reference's demo task
  * (src/main.rs:65-76).  `seconds` receives the wall time of the whole call (file read included). */
 s2k_status s2k_run_file(s2k_ctx *ctx, const char *path, const s2k_params *params, uint64_t batch_bases,
                         s2k_counts *totals, double *seconds);

@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libs2k.so")
 ABI_SYMBOLS = [
     "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_strerror",
     "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
-    "s2k_hpc_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file",
+    "s2k_hpc_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
 ]
 
 
@@ -122,6 +122,8 @@ def load_library(path=None):
     L.s2k_fastx_close.argtypes = [C.c_void_p]
     L.s2k_fastx_close.restype = None
     L.s2k_run_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Params), C.c_uint64, C.POINTER(Counts), C.POINTER(C.c_double)]
+    L.s2k_fastx_parse_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     if path is None:
         _lib = L
     return L
@@ -255,6 +257,16 @@ class Engine:
         d = cnt.as_dict()
         d["seconds"] = float(sec.value)
         return d
+
+    def parse_fastx_device(self, d_text, n_bytes, fastq, d_bases=0, bases_capacity=0, d_read_off=0, off_capacity=0):
+        """FASTA/FASTQ text in HBM -> (bases, read_off) in HBM (s2k_fastx_parse_device).  Returns (status, n_reads,
+        n_bases); status 7 (capacity) still reports the sizes needed."""
+        nr, nb = C.c_uint64(0), C.c_uint64(0)
+        st = self.lib.s2k_fastx_parse_device(self.ctx, C.c_void_p(d_text), n_bytes, 1 if fastq else 0, C.c_void_p(d_bases or 0),
+                                             bases_capacity, C.c_void_p(d_read_off or 0), off_capacity, C.byref(nr), C.byref(nb))
+        if st not in (0, 7):
+            self._check(st)
+        return st, int(nr.value), int(nb.value)
 
     def hpc_device(self, d_bases, d_read_off, n_reads, n_bases, d_hpc_off, d_hpc, d_pos, capacity):
         n = C.c_uint64(0)

@@ -98,6 +98,14 @@ struct s2k_ctx {
     s2k::HostStager stager; // pinned ring + copy threads of the host-buffer entry points
 };
 
+// context internals for the other translation units of the library (declared in s2k_hostcopy.h)
+namespace s2k {
+HostStager &ctx_stager(s2k_ctx *c) { return c->stager; }
+hipStream_t ctx_stream(s2k_ctx *c) { return c->stream; }
+int ctx_device(s2k_ctx *c) { return c->device; }
+void ctx_set_error(s2k_ctx *c, const char *what) { c->err = what; }
+} // namespace s2k
+
 namespace {
 
 s2k_status fail(s2k_ctx *c, s2k_status st, const char *what, hipError_t e = hipSuccess) {

@@ -126,4 +126,11 @@ hipError_t launch_hpc_count(const uint8_t *bases, const uint64_t *read_off, uint
 hipError_t launch_hpc_write(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, const uint64_t *hpc_off,
                             uint8_t *o_hpc, uint32_t *o_pos, uint64_t capacity, hipStream_t st);
 
+// FASTA/FASTQ record splitting in HBM (s2k_fastx_dev.hip).  count: totals = {records, sequence bytes, syntax errors};
+// write: bases + read_off (n_records + 1 entries).  `ws` holds fx_ws_bytes(n) bytes and must survive both phases.
+size_t fx_ws_bytes(uint64_t n);
+hipError_t fx_parse_count(const uint8_t *d_raw, uint64_t n, int fastq, void *ws, uint64_t *d_totals, hipStream_t st);
+hipError_t fx_parse_write(const uint8_t *d_raw, uint64_t n, int fastq, void *ws, uint64_t *d_totals, uint8_t *d_bases,
+                          uint64_t bases_cap, uint64_t *d_read_off, uint64_t off_cap, hipStream_t st);
+
 } // namespace s2k

@@ -4,8 +4,14 @@
 // records are appended to a batch (bases back to back + read_off) in pinned host memory and the batch is what
 // crosses PCIe.  Two batches are in flight: while the GPU works on one, the host parses the next.
 #include "../../include/s2k.h"
+#include "s2k_dev.h"
+#include "s2k_hostcopy.h"
 
 #include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
@@ -103,6 +109,96 @@ struct s2k_fastx {
     }
 };
 
+
+namespace {
+
+// Read-only window over a file (pread), used to find record starts near a batch boundary without parsing.
+struct FileWindow {
+    int fd;
+    uint64_t fsize, lo = 0, hi = 0;
+    std::vector<char> buf;
+    FileWindow(int f, uint64_t n) : fd(f), fsize(n) {}
+    uint64_t load(uint64_t a, uint64_t b) { // makes [a, min(b, fsize)) available; returns its length
+        if (b > fsize) b = fsize;
+        if (a >= b) {
+            lo = hi = a;
+            return 0;
+        }
+        buf.resize(b - a);
+        uint64_t got = 0;
+        while (got < b - a) {
+            const ssize_t r = pread(fd, buf.data() + got, b - a - got, (off_t)(a + got));
+            if (r <= 0) break;
+            got += (uint64_t)r;
+        }
+        lo = a;
+        hi = a + got;
+        return got;
+    }
+    char at(uint64_t p) const { return buf[p - lo]; }
+    // position after the next '\n' at or after p, or ~0 if the window ends first
+    uint64_t next_line(uint64_t p) const {
+        if (p >= hi) return ~0ull;
+        const char *q = (const char *)memchr(buf.data() + (p - lo), '\n', hi - p);
+        return q ? lo + (uint64_t)(q - buf.data()) + 1 : ~0ull;
+    }
+};
+
+// is there a record starting at p (p is a line start inside the window)?
+bool record_at(const FileWindow &w, uint64_t p, bool fastq) {
+    if (p >= w.hi) return false;
+    if (!fastq) return w.at(p) == '>';
+    if (w.at(p) != '@') return false;
+    // a quality line may start with '@' too; a header is followed by the sequence line and then a '+' line
+    const uint64_t l2 = w.next_line(p);
+    if (l2 == ~0ull) return false;
+    const uint64_t l3 = w.next_line(l2);
+    if (l3 == ~0ull || l3 >= w.hi) return false;
+    return w.at(l3) == '+';
+}
+
+// Largest record start in (after, want] if there is one, else the first record start after `want`, else the file size.
+uint64_t find_record_start(FileWindow &w, uint64_t after, uint64_t want, bool fastq) {
+    if (want >= w.fsize) return w.fsize;
+    const uint64_t slack = 1u << 20; // look-ahead needed to verify a FASTQ header near `want`
+    for (uint64_t span = 4u << 20;; span *= 4) {
+        const uint64_t a = want > after + span ? want - span : after;
+        w.load(a, want + slack);
+        // walk line starts backwards from `want`
+        uint64_t p = want + 1 < w.hi ? want + 1 : w.hi; // byte want-1 may be the newline that makes `want` a line start
+        while (p > a + 1) {
+            const char *base = w.buf.data();
+            const void *q = memrchr(base, '\n', p - 1 - w.lo);
+            if (!q) break;
+            const uint64_t ls = w.lo + (uint64_t)((const char *)q - base) + 1; // a line starts here
+            if (ls <= after) break;
+            if (ls <= want && record_at(w, ls, fastq)) return ls;
+            p = ls;
+        }
+        if (a == after) break;
+    }
+    // a single record longer than the batch: extend forward to its end
+    uint64_t from = want;
+    for (uint64_t span = 16u << 20; from < w.fsize; span *= 2) {
+        w.load(from, from + span);
+        uint64_t p = from;
+        uint64_t last_checked = from;
+        for (;;) {
+            const uint64_t ls = w.next_line(p);
+            if (ls == ~0ull || ls >= w.hi) break;
+            if (record_at(w, ls, fastq)) return ls;
+            // FASTQ candidates too close to the window end cannot be verified; restart there with a bigger window
+            p = ls;
+            last_checked = ls;
+        }
+        if (w.hi >= w.fsize) return w.fsize;
+        from = last_checked > from ? last_checked - 1 : w.hi - 1; // keep the '\n' before the next line start in view
+    }
+    return w.fsize;
+}
+
+} // namespace
+
 extern "C" {
 
 s2k_fastx *s2k_fastx_open(const char *path, s2k_status *status) {
@@ -195,24 +291,92 @@ s2k_status s2k_fastx_next(s2k_fastx *rd, uint64_t max_bases, uint64_t max_reads,
     return S2K_OK;
 }
 
+s2k_status s2k_fastx_parse_device(s2k_ctx *ctx, const uint8_t *d_text, uint64_t n_bytes, int format, uint8_t *d_bases,
+                                  uint64_t bases_capacity, uint64_t *d_read_off, uint64_t off_capacity,
+                                  uint64_t *n_reads, uint64_t *n_bases) {
+    if (!ctx || !n_reads || !n_bases || (format != S2K_FASTA && format != S2K_FASTQ)) return S2K_ERR_INVALID_ARG;
+    *n_reads = *n_bases = 0;
+    if (n_bytes && !d_text) return S2K_ERR_INVALID_ARG;
+    if (((uintptr_t)d_text & 15) || n_bytes >= (1ull << 32)) {
+        s2k::ctx_set_error(ctx, "text must be 16-byte aligned and shorter than 4 GiB");
+        return S2K_ERR_INVALID_ARG;
+    }
+    if (hipSetDevice(s2k::ctx_device(ctx)) != hipSuccess) return S2K_ERR_DEVICE;
+    hipStream_t st = s2k::ctx_stream(ctx);
+    void *ws = nullptr;
+    uint64_t *d_tot = nullptr, h_tot[3] = {0, 0, 0};
+    s2k_status rc = S2K_OK;
+    if (hipMalloc(&ws, s2k::fx_ws_bytes(n_bytes)) != hipSuccess || hipMalloc((void **)&d_tot, 3 * sizeof(uint64_t)) != hipSuccess)
+        rc = S2K_ERR_NOMEM;
+    if (rc == S2K_OK && (s2k::fx_parse_count(d_text, n_bytes, format == S2K_FASTQ, ws, d_tot, st) != hipSuccess ||
+                         hipMemcpyAsync(h_tot, d_tot, sizeof h_tot, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                         hipStreamSynchronize(st) != hipSuccess))
+        rc = S2K_ERR_DEVICE;
+    if (rc == S2K_OK) {
+        *n_reads = h_tot[0];
+        *n_bases = h_tot[1];
+        if (h_tot[2]) {
+            s2k::ctx_set_error(ctx, "malformed FASTA/FASTQ text (FASTQ must be strict 4-line records)");
+            rc = S2K_ERR_INVALID_ARG;
+        } else if (h_tot[1] > bases_capacity || h_tot[0] + 1 > off_capacity || !d_bases || !d_read_off) {
+            rc = S2K_ERR_CAPACITY; // *n_reads / *n_bases hold what is needed
+        } else if (s2k::fx_parse_write(d_text, n_bytes, format == S2K_FASTQ, ws, d_tot, d_bases, bases_capacity, d_read_off,
+                                       off_capacity, st) != hipSuccess ||
+                   hipStreamSynchronize(st) != hipSuccess)
+            rc = S2K_ERR_DEVICE;
+    }
+    if (ws) (void)hipFree(ws);
+    if (d_tot) (void)hipFree(d_tot);
+    return rc;
+}
+
 s2k_status s2k_run_file(s2k_ctx *ctx, const char *path, const s2k_params *params, uint64_t batch_bases,
                         s2k_counts *totals, double *seconds) {
-    if (!ctx || !params || !totals) return S2K_ERR_INVALID_ARG;
+    if (!ctx || !params || !totals || !path) return S2K_ERR_INVALID_ARG;
     auto t_start = std::chrono::steady_clock::now();
-    s2k_status st;
-    s2k_fastx *rd = s2k_fastx_open(path, &st);
-    if (!rd) return st;
-    if (batch_bases == 0) batch_bases = 256ull << 20;
     memset(totals, 0, sizeof *totals);
-    // two device-side batches so that parsing + H2D of batch i+1 overlap the kernels of batch i
-    struct Dev {
-        void *bases = nullptr, *off = nullptr, *out = nullptr;
-        size_t cb = 0, co = 0, cout = 0;
-    } dev[2];
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t copied[2] = {nullptr, nullptr};
-    bool ok = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; ok && i < 2; i++) ok = hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) == hipSuccess;
+    if (seconds) *seconds = 0;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        s2k::ctx_set_error(ctx, "cannot open file");
+        return S2K_ERR_INVALID_ARG;
+    }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+        close(fd);
+        return S2K_ERR_INVALID_ARG;
+    }
+    const uint64_t fsize = (uint64_t)sb.st_size;
+    FileWindow fw(fd, fsize);
+    // format from the first non-blank byte (as s2k_fastx_open)
+    uint64_t pos = 0;
+    int fastq = -1;
+    while (pos < fsize && fastq < 0) {
+        const uint64_t n = fw.load(pos, pos + (1u << 16));
+        if (!n) break;
+        for (uint64_t i = 0; i < n && fastq < 0; i++, pos++) {
+            const char c = fw.at(pos);
+            if (c == '\n' || c == '\r') continue;
+            fastq = c == '@' ? 1 : c == '>' ? 0 : 2;
+        }
+        if (fastq >= 0) pos--; // pos = first byte of the first record
+    }
+    if (fastq == 2 || hipSetDevice(s2k::ctx_device(ctx)) != hipSuccess) {
+        close(fd);
+        if (fastq == 2) s2k::ctx_set_error(ctx, "not a FASTA/FASTQ file");
+        return fastq == 2 ? S2K_ERR_INVALID_ARG : S2K_ERR_DEVICE;
+    }
+    if (batch_bases == 0) batch_bases = 256ull << 20;
+    // bytes of text per batch: FASTA is ~1 byte per base, FASTQ carries a quality string per read
+    uint64_t chunk = fastq == 1 ? 2 * batch_bases + batch_bases / 8 : batch_bases + batch_bases / 64;
+    if (chunk < (1u << 20)) chunk = 1u << 20;
+    if (chunk > (3ull << 30)) chunk = 3ull << 30;
+
+    struct Slot { // two batches in flight: staging + splitting of batch i+1 overlap the k-min-mer kernels of batch i
+        void *raw = nullptr, *ws = nullptr, *bases = nullptr, *off = nullptr, *out = nullptr;
+        size_t craw = 0, cws = 0, cb = 0, co = 0, cout = 0;
+        uint64_t nr = 0, nb = 0;
+    } slot[2];
     auto grow = [&](void *&p, size_t &cap, size_t need) -> bool {
         if (need <= cap) return true;
         if (p) (void)hipFree(p);
@@ -222,14 +386,45 @@ s2k_status s2k_run_file(s2k_ctx *ctx, const char *path, const s2k_params *params
         cap = need + need / 8 + 4096;
         return true;
     };
-    st = ok ? S2K_OK : S2K_ERR_DEVICE;
-    bool pending = false;
-    int slot = 0;
-    auto collect = [&]() -> s2k_status { // wait for the batch in flight and add its counts
-        if (!pending) return S2K_OK;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t parsed = nullptr;
+    uint64_t *d_tot = nullptr, *h_tot = nullptr;
+    bool ok = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&parsed, hipEventDisableTiming) == hipSuccess &&
+              hipMalloc((void **)&d_tot, 3 * sizeof(uint64_t)) == hipSuccess &&
+              hipHostMalloc((void **)&h_tot, 3 * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+    s2k_status st = ok ? S2K_OK : S2K_ERR_DEVICE;
+
+    auto launch = [&](Slot &d, uint64_t cap, bool wait) -> s2k_status { // k-min-mers of the batch held by slot d
+        const size_t out_bytes = (((d.nr + 1) * 8 + 255) & ~(size_t)255) + cap * (8 + 4 + 4 + 1) + 1024;
+        if (!grow(d.out, d.cout, out_bytes)) return S2K_ERR_NOMEM;
+        s2k_device_out o;
+        memset(&o, 0, sizeof o);
+        char *q = (char *)d.out;
+        o.km_capacity = cap;
+        o.km_off = (uint64_t *)q;
+        q += ((d.nr + 1) * 8 + 255) & ~(size_t)255;
+        o.hash = (uint64_t *)q;
+        q += cap * 8;
+        o.start = (uint32_t *)q;
+        q += cap * 4;
+        o.end = (uint32_t *)q;
+        q += cap * 4;
+        o.rev = (uint8_t *)q;
+        s2k_counts c;
+        return s2k_extract_device(ctx, (const uint8_t *)d.bases, (const uint64_t *)d.off, d.nr, d.nb, params, &o, wait ? &c : nullptr);
+    };
+    int pending = -1; // slot whose extraction is in flight
+    auto collect = [&]() -> s2k_status {
+        if (pending < 0) return S2K_OK;
+        Slot &d = slot[pending];
+        pending = -1;
         s2k_counts c;
         s2k_status s2 = s2k_sync(ctx, &c);
-        pending = false;
+        if (s2 == S2K_ERR_CAPACITY) { // denser than estimated (low-complexity input): k-min-mers <= bases always fits
+            s2 = launch(d, d.nb + 1, false);
+            if (s2 == S2K_OK) s2 = s2k_sync(ctx, &c);
+        }
         if (s2 != S2K_OK) return s2;
         totals->n_reads += c.n_reads;
         totals->n_bases += c.n_bases;
@@ -240,60 +435,84 @@ s2k_status s2k_run_file(s2k_ctx *ctx, const char *path, const s2k_params *params
         totals->path = c.path;
         return S2K_OK;
     };
-    while (st == S2K_OK) {
-        const uint8_t *hb;
-        const uint64_t *ho;
-        uint64_t nr = 0;
-        st = s2k_fastx_next(rd, batch_bases, 0, &hb, &ho, &nr); // overlaps the GPU work of the previous batch
-        if (st != S2K_OK || nr == 0) break;
-        const uint64_t nb = ho[nr];
-        for (uint64_t r = 0; r < nr; r++)
-            if (ho[r + 1] - ho[r] > 0xFFFFFFFEull) st = S2K_ERR_READ_TOO_LONG;
-        if (st != S2K_OK) break;
-        Dev &d = dev[slot];
-        // output capacity: k-min-mers <= minimizers <= bases, so nb + 1 can never overflow (low-complexity input included)
-        const uint64_t cap = nb + 1;
-        const size_t out_bytes = (((nr + 1) * 8 + 255) & ~(size_t)255) + cap * (8 + 4 + 4 + 1) + 1024;
-        if (!grow(d.bases, d.cb, nb + 256) || !grow(d.off, d.co, (nr + 1) * 8) || !grow(d.out, d.cout, out_bytes)) {
+
+    int cur = 0;
+    while (st == S2K_OK && pos < fsize) {
+        const uint64_t end = find_record_start(fw, pos, pos + chunk, fastq == 1);
+        const uint64_t n = end - pos;
+        if (n >= (1ull << 32)) {
+            s2k::ctx_set_error(ctx, "a single record of 4 GiB or more");
+            st = S2K_ERR_READ_TOO_LONG;
+            break;
+        }
+        Slot &d = slot[cur];
+        if (!grow(d.raw, d.craw, n + 64) || !grow(d.ws, d.cws, s2k::fx_ws_bytes(n))) {
             st = S2K_ERR_NOMEM;
             break;
         }
-        ok = hipMemcpyAsync(d.bases, hb, nb, hipMemcpyHostToDevice, copy_stream) == hipSuccess &&
-             hipMemcpyAsync(d.off, ho, (nr + 1) * 8, hipMemcpyHostToDevice, copy_stream) == hipSuccess &&
-             hipStreamSynchronize(copy_stream) == hipSuccess; // the copy overlaps the previous batch's kernels
-        if (!ok) {
+        // file -> pinned ring (several threads pread disjoint ranges) -> HBM, then the record splitter, all on copy_stream
+        const uint64_t file_off = pos;
+        hipError_t e = s2k::ctx_stager(ctx).h2d_fill(d.raw, n, copy_stream, [&](char *dst, size_t off, size_t len) {
+            while (len) {
+                const ssize_t got = pread(fd, dst, len, (off_t)(file_off + off));
+                if (got <= 0) return false;
+                dst += got;
+                off += (size_t)got;
+                len -= (size_t)got;
+            }
+            return true;
+        });
+        if (e == hipSuccess) e = s2k::fx_parse_count((const uint8_t *)d.raw, n, fastq == 1, d.ws, d_tot, copy_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_tot, d_tot, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, copy_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(copy_stream);
+        if (e != hipSuccess) {
             st = S2K_ERR_DEVICE;
             break;
         }
-        st = collect(); // previous batch done
+        if (h_tot[2]) {
+            s2k::ctx_set_error(ctx, "malformed FASTA/FASTQ text (FASTQ must be strict 4-line records)");
+            st = S2K_ERR_INVALID_ARG;
+            break;
+        }
+        d.nr = h_tot[0];
+        d.nb = h_tot[1];
+        if (!grow(d.bases, d.cb, d.nb + 256) || !grow(d.off, d.co, (d.nr + 1) * 8)) {
+            st = S2K_ERR_NOMEM;
+            break;
+        }
+        e = s2k::fx_parse_write((const uint8_t *)d.raw, n, fastq == 1, d.ws, d_tot, (uint8_t *)d.bases, d.nb, (uint64_t *)d.off,
+                                d.nr + 1, copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(parsed, copy_stream);
+        if (e != hipSuccess) {
+            st = S2K_ERR_DEVICE;
+            break;
+        }
+        st = collect(); // previous batch done (its kernels ran while this one was staged and split)
         if (st != S2K_OK) break;
-        s2k_device_out o;
-        memset(&o, 0, sizeof o);
-        char *q = (char *)d.out;
-        o.km_capacity = cap;
-        o.km_off = (uint64_t *)q;
-        q += ((nr + 1) * 8 + 255) & ~(size_t)255;
-        o.hash = (uint64_t *)q;
-        q += cap * 8;
-        o.start = (uint32_t *)q;
-        q += cap * 4;
-        o.end = (uint32_t *)q;
-        q += cap * 4;
-        o.rev = (uint8_t *)q;
-        st = s2k_extract_device(ctx, (const uint8_t *)d.bases, (const uint64_t *)d.off, nr, nb, params, &o, nullptr);
-        pending = st == S2K_OK;
-        slot ^= 1;
+        if (hipStreamWaitEvent(s2k::ctx_stream(ctx), parsed, 0) != hipSuccess) {
+            st = S2K_ERR_DEVICE;
+            break;
+        }
+        // output capacity: three times the expected minimizer density, exact retry in collect() if that is too small
+        double dens = params->density < 0 ? 0 : params->density > 1 ? 1 : params->density;
+        uint64_t cap = (uint64_t)((double)d.nb * dens * 3.0) + 2 * d.nr + (1u << 16);
+        if (cap > d.nb + 1) cap = d.nb + 1;
+        st = launch(d, cap, false);
+        if (st == S2K_OK) pending = cur;
+        pos = end;
+        cur ^= 1;
     }
     if (st == S2K_OK) st = collect();
     else (void)s2k_sync(ctx, nullptr);
-    for (int i = 0; i < 2; i++) {
-        if (dev[i].bases) (void)hipFree(dev[i].bases);
-        if (dev[i].off) (void)hipFree(dev[i].off);
-        if (dev[i].out) (void)hipFree(dev[i].out);
-        if (copied[i]) (void)hipEventDestroy(copied[i]);
-    }
+    if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+    for (auto &d : slot)
+        for (void *p : {d.raw, d.ws, d.bases, d.off, d.out})
+            if (p) (void)hipFree(p);
+    if (parsed) (void)hipEventDestroy(parsed);
+    if (d_tot) (void)hipFree(d_tot);
+    if (h_tot) (void)hipHostFree(h_tot);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
-    s2k_fastx_close(rd);
+    close(fd);
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     return st;
 }

@@ -22,6 +22,8 @@ public:
     explicit CopyPool(int threads);
     ~CopyPool();
     void copy(void *dst, const void *src, size_t bytes); // returns when done
+    // runs fn(begin, end) on 4 KiB-aligned slices of [0, bytes), one slice per thread; returns when all are done
+    void slices(size_t bytes, const std::function<void(size_t, size_t)> &fn);
     int threads() const { return (int)workers_.size() + 1; }
 
 private:
@@ -32,8 +34,7 @@ private:
     uint64_t gen_ = 0;
     int remaining_ = 0;
     bool stop_ = false;
-    char *dst_ = nullptr;
-    const char *src_ = nullptr;
+    const std::function<void(size_t, size_t)> *fn_ = nullptr;
     size_t bytes_ = 0;
 };
 
@@ -46,6 +47,10 @@ public:
     // pageable host -> device.  On return every byte of `src` has been read (the caller may reuse it) and the last
     // DMA is queued on `s`; work queued on `s` afterwards sees the data.
     hipError_t h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);
+    // same, the source being produced piecewise: fill(pinned_dst, offset, n) must write source bytes
+    // [offset, offset+n) to pinned_dst (called from several threads on disjoint ranges); false aborts.
+    hipError_t h2d_fill(void *dst_dev, size_t bytes, hipStream_t s,
+                        const std::function<bool(char *, size_t, size_t)> &fill);
     // device -> pageable host, ordered after the work already queued on `s`.  On return `dst` is complete.
     hipError_t d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
 
@@ -61,4 +66,12 @@ private:
     CopyPool *pool_ = nullptr;
 };
 
+} // namespace s2k
+
+struct s2k_ctx;
+namespace s2k { // context internals shared inside the library (defined in s2k_api.hip)
+HostStager &ctx_stager(s2k_ctx *c);
+hipStream_t ctx_stream(s2k_ctx *c);
+int ctx_device(s2k_ctx *c);
+void ctx_set_error(s2k_ctx *c, const char *what);
 } // namespace s2k

@@ -1,6 +1,7 @@
 // Pinned-ring staging between pageable host memory and HBM; see s2k_hostcopy.h.
 #include "s2k_hostcopy.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -30,21 +31,19 @@ static inline void slice_of(size_t bytes, int parts, int idx, size_t *b, size_t 
 void CopyPool::worker(int idx) {
     uint64_t seen = 0;
     for (;;) {
-        char *d;
-        const char *s;
+        const std::function<void(size_t, size_t)> *fn;
         size_t n;
         {
             std::unique_lock<std::mutex> g(m_);
             cv_.wait(g, [&] { return gen_ != seen; });
             seen = gen_;
             if (stop_) return;
-            d = dst_;
-            s = src_;
+            fn = fn_;
             n = bytes_;
         }
         size_t b, e;
         slice_of(n, threads(), idx, &b, &e);
-        if (e > b) memcpy(d + b, s + b, e - b);
+        if (e > b) (*fn)(b, e);
         {
             std::lock_guard<std::mutex> g(m_);
             if (--remaining_ == 0) done_cv_.notify_one();
@@ -52,16 +51,15 @@ void CopyPool::worker(int idx) {
     }
 }
 
-void CopyPool::copy(void *dst, const void *src, size_t bytes) {
+void CopyPool::slices(size_t bytes, const std::function<void(size_t, size_t)> &fn) {
     const int T = threads();
     if (T == 1 || bytes < (256u << 10)) {
-        memcpy(dst, src, bytes);
+        if (bytes) fn(0, bytes);
         return;
     }
     {
         std::lock_guard<std::mutex> g(m_);
-        dst_ = (char *)dst;
-        src_ = (const char *)src;
+        fn_ = &fn;
         bytes_ = bytes;
         remaining_ = T - 1;
         gen_++;
@@ -69,9 +67,13 @@ void CopyPool::copy(void *dst, const void *src, size_t bytes) {
     cv_.notify_all();
     size_t b, e;
     slice_of(bytes, T, 0, &b, &e);
-    if (e > b) memcpy((char *)dst + b, (const char *)src + b, e - b);
+    if (e > b) fn(b, e);
     std::unique_lock<std::mutex> g(m_);
     done_cv_.wait(g, [&] { return remaining_ == 0; });
+}
+
+void CopyPool::copy(void *dst, const void *src, size_t bytes) {
+    slices(bytes, [&](size_t b, size_t e) { memcpy((char *)dst + b, (const char *)src + b, e - b); });
 }
 
 HostStager::~HostStager() {
@@ -116,6 +118,15 @@ hipError_t HostStager::h2d(void *dst_dev, const void *src_host, size_t bytes, hi
         hipError_t e = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s);
         return e != hipSuccess ? e : hipStreamSynchronize(s); // pageable source: the caller may reuse it on return
     }
+    return h2d_fill(dst_dev, bytes, s, [&](char *pin, size_t off, size_t n) {
+        memcpy(pin, (const char *)src_host + off, n);
+        return true;
+    });
+}
+
+hipError_t HostStager::h2d_fill(void *dst_dev, size_t bytes, hipStream_t s,
+                                const std::function<bool(char *, size_t, size_t)> &fill) {
+    if (bytes == 0) return hipSuccess;
     hipError_t e = init();
     if (e != hipSuccess) return e;
     size_t off = 0;
@@ -123,8 +134,13 @@ hipError_t HostStager::h2d(void *dst_dev, const void *src_host, size_t bytes, hi
         const int slot = i % kSlots;
         const size_t n = bytes - off < kChunk ? bytes - off : kChunk;
         if ((e = hipEventSynchronize(ev_[slot])) != hipSuccess) return e;
-        pool_->copy(pin_[slot], (const char *)src_host + off, n);
-        if ((e = hipMemcpyAsync((char *)dst_dev + off, pin_[slot], n, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+        std::atomic<bool> ok{true};
+        char *pin = pin_[slot];
+        pool_->slices(n, [&](size_t b, size_t en) {
+            if (!fill(pin + b, off + b, en - b)) ok = false;
+        });
+        if (!ok) return hipErrorUnknown;
+        if ((e = hipMemcpyAsync((char *)dst_dev + off, pin, n, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev_[slot], s)) != hipSuccess) return e;
         off += n;
     }

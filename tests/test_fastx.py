@@ -104,6 +104,92 @@ def test_run_file_matches_oracle(tmp_path, oracle):
     eng.close()
 
 
+def _gpu_split(eng, text, fastq):
+    """record splitting on the GPU; returns the list of reads"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    t = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()).to(dev) if len(text) else torch.zeros(16, dtype=torch.uint8, device=dev)
+    st, nr, nb = eng.parse_fastx_device(t.data_ptr(), len(text), fastq)
+    assert st == 7 or (nr == 0 and nb == 0)  # no output buffers given: sizes only
+    d_b = torch.zeros(nb + 16, dtype=torch.uint8, device=dev)
+    d_o = torch.zeros(nr + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    st, nr2, nb2 = eng.parse_fastx_device(t.data_ptr(), len(text), fastq, d_b.data_ptr(), nb, d_o.data_ptr(), nr + 1)
+    assert (st, nr2, nb2) == (0, nr, nb)
+    b, o = d_b.cpu().numpy(), d_o.cpu().numpy()
+    assert int(o[-1]) == nb and (b[nb:] == 0).all()
+    return [b[int(o[r]):int(o[r + 1])].tobytes() for r in range(nr)]
+
+
+@pytest.mark.gpu
+def test_gpu_record_splitting_equals_host_parser(tmp_path):
+    """s2k_fastx_parse_device (records split in HBM) against the host parser and the reads that were written"""
+    eng = pkg.Engine(0)
+    rng = np.random.default_rng(11)
+    reads = _reads(rng, 301, maxlen=9000) + [b"", b"A", b"ACGT" * 5000]
+    for width, crlf, trail in ((0, False, True), (60, False, True), (70, True, True), (0, False, False), (13, False, False), (4096, False, True)):
+        p = tmp_path / "x.fa"
+        _write_fasta(p, reads, width, crlf, trail)
+        got = _gpu_split(eng, p.read_bytes(), fastq=False)
+        assert got == reads == _collect(p, 1 << 30)[0], (width, crlf, trail)
+    p = tmp_path / "x.fq"
+    _write_fastq(p, reads)
+    text = p.read_bytes()
+    assert _gpu_split(eng, text, fastq=True) == reads
+    assert _gpu_split(eng, text + b"\n\n", fastq=True) == reads  # trailing blank lines
+    # quality strings full of '@' and '>' must not be taken for headers
+    with open(p, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@r%d\n%s\n+r%d\n%s\n" % (i, r, i, (b"@>+" * len(r))[:len(r)]))
+    assert _gpu_split(eng, p.read_bytes(), fastq=True) == reads
+    # blank lines between FASTA records, empty text, header-only text
+    assert _gpu_split(eng, b">a\nAC\n\n>b\n\nGT\nT\n", fastq=False) == [b"AC", b"GTT"]
+    assert _gpu_split(eng, b"", fastq=False) == []
+    assert _gpu_split(eng, b">only a header", fastq=False) == [b""]
+    # malformed FASTQ is reported, not mis-parsed
+    import torch
+
+    bad = b"@r1\nACGT\nIIII\n@r2\nAC\n+\nII\n"
+    t = torch.from_numpy(np.frombuffer(bad, dtype=np.uint8).copy()).cuda()
+    with pytest.raises(pkg.S2kError):
+        eng.parse_fastx_device(t.data_ptr(), len(bad), True)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_run_file_many_batches_fasta_and_fastq(tmp_path, oracle):
+    """file mode with batch boundaries falling inside records (the driver must cut at record starts), FASTA with
+    wrapped lines and one record much longer than a batch, FASTQ with '@' in the qualities"""
+    from oracle import s2k_oracle as so
+
+    rng = np.random.default_rng(17)
+    reads = _reads(rng, 900, maxlen=12000) + [bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=3_300_000)])] + _reads(rng, 50, 5000)
+    bases, off = pkg.pack_reads(reads)
+    ref = oracle.batch(bases, off, 31, 7, 0.01, so.HPC, threads=8)
+    want = (len(reads), len(bases), ref["n"], int(np.bitwise_xor.reduce(ref["hash"])))
+    eng = pkg.Engine(0)
+    fa, fq = tmp_path / "r.fa", tmp_path / "r.fq"
+    _write_fasta(fa, reads, width=61)
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, r, (b"@I" * len(r))[:len(r)]))
+    for path in (fa, fq):
+        for batch in (1 << 20, 1 << 30):
+            tot = eng.run_file(str(path), 31, 7, 0.01, pkg.HashMode.Hpc, batch_bases=batch)
+            assert (tot["n_reads"], tot["n_bases"], tot["n_kminmers"], tot["xor_hash"]) == want, (path.name, batch)
+    # low-complexity input: far more k-min-mers than the density-based capacity guess -> exact retry inside the driver
+    lc = tmp_path / "lc.fa"
+    reads2 = [b"ACGT" * 20000 for _ in range(40)]
+    _write_fasta(lc, reads2)
+    b2, o2 = pkg.pack_reads(reads2)
+    for d in (0.01, 1.0):
+        r2 = oracle.batch(b2, o2, 31, 7, d, so.REGULAR, threads=8)
+        tot = eng.run_file(str(lc), 31, 7, d, pkg.HashMode.Regular)
+        assert tot["n_kminmers"] == r2["n"] and tot["xor_hash"] == (int(np.bitwise_xor.reduce(r2["hash"])) if r2["n"] else 0)
+    eng.close()
+
+
 @pytest.mark.gpu
 def test_cli_demo_and_file_mode(tmp_path, oracle):
     """src/main.rs:13-48 (demo) and :51-83 (file mode) through the C++ driver."""
