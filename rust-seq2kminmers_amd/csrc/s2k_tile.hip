@@ -853,10 +853,10 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
     return N;
 }
 
-// Persistent kernel: every wave walks tiles t = wave_id, wave_id + n_waves, ...  While a tile is being
-// hashed, the next tile's 9344 bytes are already in flight into registers (NPRE x 16 B per lane), and the
-// read-table entries of the current tile are fetched before they are needed, so no global-load latency
-// sits on the critical path except in the first iteration.
+// Persistent kernel: every wave walks tiles t = wave_id, wave_id + n_waves, ...  As soon as a tile's dense phase
+// is over the next tile's 9344 bytes are requested straight into the wave's LDS buffer (LDS-direct loads, no
+// staging registers); the other waves of the SIMD cover that latency.  The read-table entries of the next tile
+// are fetched one iteration ahead, so no dependent global load is waited for on the spot.
 template <int L, bool HPC>
 __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
@@ -887,21 +887,23 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
     // a tile is "full" when the tile and its 128 B look-ahead lie inside the stream: staged branch-free
     auto is_full = [&](uint64_t tt) { return (tt + 1) * (uint64_t)TILE_BASES + 128 <= n_bases; };
     // Software pipeline over this wave's tiles (cur = t, nxt = t + n_waves, nn = t + 2 n_waves):
-    //   pre[], prevb      : bases of nxt, issued while cur is hashed
+    //   LDS buffer, prevb : bases of nxt, requested at the end of cur
     //   r0n, r1n          : tile_read0 of nxt   (issued one iteration earlier, so their values are usable ...)
-    //   bposn, rs0n       : read_off[r0n + 1 + lane], read_off[r0n]   (... to address these, issued with pre[])
+    //   bposn, rs0n       : read_off[r0n + 1 + lane], read_off[r0n]   (... to address these during cur)
     //   r0nn, r1nn        : tile_read0 of nn
-    // so no dependent global load is waited for on the spot after the prologue.
-    uint4 pre[NPRE];
     uint32_t prevb = 0;
     bool have_pre = false;
-    auto prefetch = [&](uint64_t tt) { // issue the loads for tile tt; nothing waits here
+    // stage tile tt: NPRE x 1 KiB go from HBM straight into this wave's LDS buffer (global_load_lds_dwordx4: lane i
+    // of load r lands at D + 1024 r + 16 i), no staging registers; nothing waits here
+    auto stage_direct = [&](uint64_t tt) {
         const uint8_t *g = bases + tt * (uint64_t)TILE_BASES;
+        typedef const __attribute__((address_space(1))) void *gptr;
+        typedef __attribute__((address_space(3))) void *lptr;
 #pragma unroll
-        for (int r = 0; r < NPRE; r++) {
-            const uint32_t off = 16 * lane + 1024 * r;
-            pre[r] = (r < NPRE - 1 || lane < 8) ? *reinterpret_cast<const uint4 *>(g + off) : make_uint4(0, 0, 0, 0);
-        }
+        for (int r = 0; r < NPRE - 1; r++)
+            __builtin_amdgcn_global_load_lds((gptr)(g + 16 * lane + 1024 * r), (lptr)(D + 1024 * r), 16, 0, 0);
+        if (lane < 8)
+            __builtin_amdgcn_global_load_lds((gptr)(g + 16 * lane + 1024 * (NPRE - 1)), (lptr)(D + 1024 * (NPRE - 1)), 16, 0, 0);
         prevb = tt > 0 ? (uint32_t)g[-1] : 0u;
     };
     auto read_entries = [&](uint32_t rr0, uint64_t &bp, uint64_t &rs) {
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
     uint64_t bpos0, rs0;
     read_entries(r0, bpos0, rs0);
     if (is_full(t)) {
-        prefetch(t);
+        stage_direct(t);
         have_pre = true;
     }
     uint32_t r0n = 0, r1n = 0;
@@ -929,12 +931,16 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
         const uint32_t tile_len = rem > (uint64_t)TILE_BASES ? (uint32_t)TILE_BASES : (uint32_t)rem;
         uint32_t na = 0;
         // ---- stage the tile (+128 B look-ahead) in LDS: 1 KiB per wave-instruction ----------------------
-        if (have_pre) {
+        if (have_pre) { // issued at the end of the previous tile (or in the prologue)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (HPC) { // bit 7 doubles as the read-start mark there: note bytes that already have it
+                const uint4 *own = reinterpret_cast<const uint4 *>(D + TILE_T * lane);
 #pragma unroll
-            for (int r = 0; r < NPRE; r++) {
-                const uint32_t off = 16 * lane + 1024 * r;
-                if (r < NPRE - 1) na |= (pre[r].x | pre[r].y | pre[r].z | pre[r].w);
-                if (r < NPRE - 1 || lane < 8) *reinterpret_cast<uint4 *>(D + off) = pre[r];
+                for (int p = 0; p < TILE_T / 16; p++) {
+                    const uint4 v = own[p];
+                    na |= (v.x | v.y | v.z | v.w);
+                }
             }
         } else { // tile at the end of the stream: guarded loads, zero past the end
             const uint8_t *g = bases + t0;
@@ -981,12 +987,7 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
         uint64_t bposn = ~0ull, rs0n = 0;
         uint32_t r0nn = 0, r1nn = 0;
         auto issue_next = [&]() {
-            have_pre = false;
             if (t + n_waves < n_tiles) {
-                if (is_full(t + n_waves)) {
-                    prefetch(t + n_waves);
-                    have_pre = true;
-                }
                 read_entries(r0n, bposn, rs0n);
                 if (t + 2 * n_waves < n_tiles) {
                     r0nn = tile_read0[t + 2 * n_waves];
@@ -1016,6 +1017,11 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
             tile_rec_off[t] = base;
         }
         wave_sync(); // LDS of this wave is reused by the next tile
+        have_pre = false;
+        if (t + n_waves < n_tiles && is_full(t + n_waves)) {
+            stage_direct(t + n_waves);
+            have_pre = true;
+        }
         r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; // rotate the pipeline
         S2K_STAMP(6); // tail
     }
