@@ -38,7 +38,7 @@
 //    shared overflow region with one atomic.  (One shared cursor for every tile serialised the kernel.)
 //
 // Diagnostics: S2K_DEBUG_SKIP (bit 1 skip hash loop, 2 skip dense phase, 4 skip compaction, 8 per-phase cycle
-// stamps printed by the host, 16/32/64 skip stores / per-read counts / re-derivation) and
+// stamps printed by the host -- only in builds made with `make PROFILE=1` --, 16/32/64 skip stores / per-read counts / re-derivation) and
 // S2K_DEBUG_BLOCKS_PER_CU are timing ablations only -- results are wrong when a skip bit is set.
 #include "s2k_dev.h"
 
@@ -51,7 +51,8 @@ namespace {
 constexpr int TW = 4;                                  // waves per block (they share the two seed tables)
 constexpr int HS_OFF = 16;                             // data starts here; byte HS_OFF-1 absorbs "slot -1" stores
 constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window slack
-constexpr int NPC = TILE_T / 8;                        // 18 capture pieces per lane
+constexpr int CAPP = 16;                               // positions per capture piece
+constexpr int NPC = TILE_T / CAPP;                     // 9 capture pieces per lane
 constexpr int MAX_L_TILED = 64;
 constexpr int LISTCAP = 512;                           // hits handled per dense batch
 constexpr int REG_LA = 2;
@@ -69,7 +70,7 @@ struct NoHpcLds {};
 template <bool HPC>
 struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
     uint8_t buf[BUF_BYTES];
-    uint32_t caps[NPC][64];  // hash of the last hit of each 8-position piece
+    uint32_t caps[NPC][64];  // hash of the last hit of each 16-position piece
     uint32_t hm[64][5];      // raw hit masks, bit x = lane-local hash position x (stored bytewise)
     uint16_t list[LISTCAP];  // validated hits of the current batch, tile-local hash positions, ascending
     uint16_t jobx[64];       // hits whose hash must be re-derived: tile-local position ...
@@ -218,7 +219,7 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], u
             rh = __builtin_rotateright32(rh, 1) ^ EO[P].y ^ EI[S].y;            // src/nthash_hpc.rs:247-249
             if constexpr (P % 8 == 7) {
                 hmb[P / 8] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-                Sx.caps[P / 8][lane] = cap;
+                if constexpr (P % CAPP == CAPP - 1) Sx.caps[P / CAPP][lane] = cap;
                 bits = 0;
             }
         }
@@ -227,7 +228,7 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], u
         const uint32_t hv = fh < rh ? fh : rh;
         hit_track(hv, bound, cap, bits);
         hmb[(T - 1) / 8] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-        Sx.caps[(T - 1) / 8][lane] = cap;
+        Sx.caps[(T - 1) / CAPP][lane] = cap;
     }
 }
 
@@ -278,7 +279,7 @@ __device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 
         rh = __builtin_rotateright32(rh, 1) ^ to.y ^ ti.y;
         if ((pos & 7) == 7) {
             hmb[pos >> 3] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-            S.caps[pos >> 3][lane] = cap;
+            if ((pos & (CAPP - 1)) == CAPP - 1) S.caps[pos / CAPP][lane] = cap;
             bits = 0;
         }
     }
@@ -306,8 +307,9 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
     }
 }
 
-// phase stamps for the S2K_DEBUG_SKIP&8 diagnostic path (never set in production runs): cycles per
-// phase are kept in registers and flushed once per tile to one of 64 shards
+// Phase stamps (cycles per phase, kept in registers and flushed once per tile to one of 64 shards) exist only in
+// builds with -DS2K_PROFILE (tools/phases.sh): the 16 accumulators cost 32 VGPRs that production kernels need.
+#ifdef S2K_PROFILE
 #define S2K_STAMP(i)                                                                     \
     do {                                                                                 \
         if (sem.dbg_skip & 8) {                                                          \
@@ -317,6 +319,9 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
             stamp = _n;                                                                  \
         }                                                                                \
     } while (0)
+#else
+#define S2K_STAMP(i) do { (void)ph; (void)stamp; } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Hpc pre-stage: in-place run-head compaction of the staged tile.  Returns R_t (run heads owned by
@@ -756,10 +761,10 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 need_re[u] = false;
                 if (act[u]) {
                     x[u] = S.list[kk[u]];
-                    const uint32_t o = __umulhi(x[u], rcpTq), bit = x[u] - o * Tq, piece = bit >> 3; // o = x / Tq
-                    const uint32_t pbyte = reinterpret_cast<const uint8_t *>(S.hm[o])[piece];
+                    const uint32_t o = __umulhi(x[u], rcpTq), bit = x[u] - o * Tq, piece = bit / CAPP; // o = x / Tq
+                    const uint32_t pbits = reinterpret_cast<const uint16_t *>(S.hm[o])[piece]; // hits of the piece, bit j <-> position j
                     // the kept hash belongs to the piece's last raw hit; pieces cut by nh may hold a stale one
-                    need_re[u] = (pbyte >> ((bit & 7) + 1)) != 0 || (Tq * o + 8 * piece + 8 > nh);
+                    need_re[u] = (pbits >> ((bit & (CAPP - 1)) + 1)) != 0 || (Tq * o + CAPP * piece + CAPP > nh);
                     hv[u] = S.caps[piece][o];
                 }
             }
@@ -768,7 +773,9 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 uint64_t jobs = __ballot(need_re[u]);
+#ifdef S2K_PROFILE
                 if (sem.dbg_skip & 8) ph[7] += (uint64_t)__popcll(jobs);
+#endif
                 if (sem.dbg_skip & 64) jobs = 0;
                 if (jobs) {
                     const uint32_t nj = (uint32_t)__popcll(jobs);
@@ -853,10 +860,10 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
     return N;
 }
 
-// Persistent kernel: every wave walks tiles t = wave_id, wave_id + n_waves, ...  As soon as a tile's dense phase
-// is over the next tile's 9344 bytes are requested straight into the wave's LDS buffer (LDS-direct loads, no
-// staging registers); the other waves of the SIMD cover that latency.  The read-table entries of the next tile
-// are fetched one iteration ahead, so no dependent global load is waited for on the spot.
+// Persistent kernel: every wave walks tiles t = wave_id, wave_id + n_waves, ...  While a tile is being
+// hashed, the next tile's 9344 bytes are already in flight into registers (NPRE x 16 B per lane), and the
+// read-table entries of the current tile are fetched before they are needed, so no global-load latency
+// sits on the critical path except in the first iteration.
 template <int L, bool HPC>
 __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
@@ -887,23 +894,21 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
     // a tile is "full" when the tile and its 128 B look-ahead lie inside the stream: staged branch-free
     auto is_full = [&](uint64_t tt) { return (tt + 1) * (uint64_t)TILE_BASES + 128 <= n_bases; };
     // Software pipeline over this wave's tiles (cur = t, nxt = t + n_waves, nn = t + 2 n_waves):
-    //   LDS buffer, prevb : bases of nxt, requested at the end of cur
+    //   pre[], prevb      : bases of nxt, issued while cur is hashed
     //   r0n, r1n          : tile_read0 of nxt   (issued one iteration earlier, so their values are usable ...)
-    //   bposn, rs0n       : read_off[r0n + 1 + lane], read_off[r0n]   (... to address these during cur)
+    //   bposn, rs0n       : read_off[r0n + 1 + lane], read_off[r0n]   (... to address these, issued with pre[])
     //   r0nn, r1nn        : tile_read0 of nn
+    // so no dependent global load is waited for on the spot after the prologue.
+    uint4 pre[NPRE];
     uint32_t prevb = 0;
     bool have_pre = false;
-    // stage tile tt: NPRE x 1 KiB go from HBM straight into this wave's LDS buffer (global_load_lds_dwordx4: lane i
-    // of load r lands at D + 1024 r + 16 i), no staging registers; nothing waits here
-    auto stage_direct = [&](uint64_t tt) {
+    auto prefetch = [&](uint64_t tt) { // issue the loads for tile tt; nothing waits here
         const uint8_t *g = bases + tt * (uint64_t)TILE_BASES;
-        typedef const __attribute__((address_space(1))) void *gptr;
-        typedef __attribute__((address_space(3))) void *lptr;
 #pragma unroll
-        for (int r = 0; r < NPRE - 1; r++)
-            __builtin_amdgcn_global_load_lds((gptr)(g + 16 * lane + 1024 * r), (lptr)(D + 1024 * r), 16, 0, 0);
-        if (lane < 8)
-            __builtin_amdgcn_global_load_lds((gptr)(g + 16 * lane + 1024 * (NPRE - 1)), (lptr)(D + 1024 * (NPRE - 1)), 16, 0, 0);
+        for (int r = 0; r < NPRE; r++) {
+            const uint32_t off = 16 * lane + 1024 * r;
+            pre[r] = (r < NPRE - 1 || lane < 8) ? *reinterpret_cast<const uint4 *>(g + off) : make_uint4(0, 0, 0, 0);
+        }
         prevb = tt > 0 ? (uint32_t)g[-1] : 0u;
     };
     auto read_entries = [&](uint32_t rr0, uint64_t &bp, uint64_t &rs) {
@@ -915,7 +920,7 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
     uint64_t bpos0, rs0;
     read_entries(r0, bpos0, rs0);
     if (is_full(t)) {
-        stage_direct(t);
+        prefetch(t);
         have_pre = true;
     }
     uint32_t r0n = 0, r1n = 0;
@@ -931,16 +936,12 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
         const uint32_t tile_len = rem > (uint64_t)TILE_BASES ? (uint32_t)TILE_BASES : (uint32_t)rem;
         uint32_t na = 0;
         // ---- stage the tile (+128 B look-ahead) in LDS: 1 KiB per wave-instruction ----------------------
-        if (have_pre) { // issued at the end of the previous tile (or in the prologue)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if constexpr (HPC) { // bit 7 doubles as the read-start mark there: note bytes that already have it
-                const uint4 *own = reinterpret_cast<const uint4 *>(D + TILE_T * lane);
+        if (have_pre) {
 #pragma unroll
-                for (int p = 0; p < TILE_T / 16; p++) {
-                    const uint4 v = own[p];
-                    na |= (v.x | v.y | v.z | v.w);
-                }
+            for (int r = 0; r < NPRE; r++) {
+                const uint32_t off = 16 * lane + 1024 * r;
+                if (r < NPRE - 1) na |= (pre[r].x | pre[r].y | pre[r].z | pre[r].w);
+                if (r < NPRE - 1 || lane < 8) *reinterpret_cast<uint4 *>(D + off) = pre[r];
             }
         } else { // tile at the end of the stream: guarded loads, zero past the end
             const uint8_t *g = bases + t0;
@@ -987,7 +988,12 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
         uint64_t bposn = ~0ull, rs0n = 0;
         uint32_t r0nn = 0, r1nn = 0;
         auto issue_next = [&]() {
+            have_pre = false;
             if (t + n_waves < n_tiles) {
+                if (is_full(t + n_waves)) {
+                    prefetch(t + n_waves);
+                    have_pre = true;
+                }
                 read_entries(r0n, bposn, rs0n);
                 if (t + 2 * n_waves < n_tiles) {
                     r0nn = tile_read0[t + 2 * n_waves];
@@ -1017,16 +1023,13 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
             tile_rec_off[t] = base;
         }
         wave_sync(); // LDS of this wave is reused by the next tile
-        have_pre = false;
-        if (t + n_waves < n_tiles && is_full(t + n_waves)) {
-            stage_direct(t + n_waves);
-            have_pre = true;
-        }
         r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; // rotate the pipeline
         S2K_STAMP(6); // tail
     }
+#ifdef S2K_PROFILE
     if ((sem.dbg_skip & 8) && lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd((unsigned long long *)&counts->dbg_cycles[blockIdx.x & 63][i], (unsigned long long)ph[i]);
+#endif
 }
 
 // tile_read0[t] = last read index r (0 <= r < n_reads) with read_off[r] <= min(t*TILE, n_bases)
