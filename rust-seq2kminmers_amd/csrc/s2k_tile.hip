@@ -1,1098 +1,17 @@
-// s2k_tile.hip -- the tiled minimizer kernel: fused homopolymer compression + 32-bit canonical ntHash1
-// + density threshold + original-space back-map, for gfx950.
-//
-// What it replaces: the per-base loop of the reference's scalar iterators
-// (NtHashHPCIterator::next, src/nthash_hpc.rs:241-278; the Regular arm, src/lib.rs:215-230), which
-// is ~100 % of the reference's time.  It is NOT a translation of either the
-// scalar loop (loop-carried over the whole read) or the AVX-512 code (16-lane Hillis-Steele scan):
-//
-//  * The batch of reads is one byte stream; the stream is cut into fixed tiles of 64 x 144 = 9216
-//    bases, one wave per tile, independent of read lengths.  l-mers that straddle a read boundary
-//    are cleared from the hit masks afterwards, so ragged reads cost nothing in the hot loop.
-//  * Persistent waves: a wave walks tiles t, t + n_waves, ...; the next tile's bytes (and the read-table
-//    entries of the next two tiles) are in flight into registers while the current tile is processed, so
-//    no global-load latency sits on the critical path after the first tile.
-//  * A tile is staged in LDS (1 KiB per wave-instruction).  Each lane then owns 144 consecutive l-mer
-//    start positions and *rolls* the hash privately (fh' = rotl(fh,1) ^ OUT[s[p]] ^ IN[s[p+l]]), reading
-//    its bytes from LDS in 16 B pieces (lane stride 16*odd bytes: bank-conflict free) and its seeds from
-//    two 256-entry LDS tables that have the rotations pre-applied (one ds_read_b64 each, one SDWA
-//    instruction per base for the address).  A lane pays an l-base warm-up instead of a cross-lane scan.
-//  * Minimizers are rare (~2 % of positions), but a per-position branch would be taken by almost every
-//    wave (64 lanes x 2 %).  So the hot loop is branch-free: per position it records a hit bit and keeps
-//    the hash of the last hit of each 8-position piece (compare -> select -> add-with-carry through VCC).
-//  * Dense phase: read starts become hash-space boundaries and invalid l-mers are cleared from the masks
-//    by range; popcounts + one DPP scan give every lane its output offset; lanes list their hits; then one
-//    lane per hit finds its read among the read starts kept in LDS, back-maps positions and writes the
-//    record with coalesced stores.  The ~7 % of hits that were not the last of their piece are queued and
-//    re-derived from their l bytes, one lane per hit.  No global LOAD sits in that loop: one would make
-//    the compiler drain every outstanding store of the previous round.
-//  * Hpc mode first compacts the tile's run heads in place in LDS (SWAR byte compares, per-lane
-//    popcounts, one wave scan, overwrite-style byte stores), appends the l run heads that follow the
-//    tile (first from the staged look-ahead, then by a loop over the stream, so arbitrarily long
-//    homopolymers are fine), and then runs the same hash loop over the compacted bytes.  Raw positions
-//    are recovered for hits only, from the per-lane flag masks (owner-lane hint table + select-nth-bit).
-//    Read starts are forced run heads: they are marked with bit 7 of the staged byte, which is why
-//    Hpc tiles require 7-bit input (a byte >= 0x80 raises `non_ascii` and the host re-runs the call on
-//    the exact serial kernels).
-//  * Records go to a fixed per-tile slab (mean + 6 sigma); only a tile with more hits takes space from a
-//    shared overflow region with one atomic.  (One shared cursor for every tile serialised the kernel.)
-//
-// Diagnostics: S2K_DEBUG_SKIP (bit 1 skip hash loop, 2 skip dense phase, 4 skip compaction, 8 per-phase cycle
-// stamps printed by the host -- only in builds made with `make PROFILE=1` --, 16/32/64 skip stores / per-read counts / re-derivation) and
-// S2K_DEBUG_BLOCKS_PER_CU are timing ablations only -- results are wrong when a skip bit is set.
-#include "s2k_dev.h"
-
-#include <cstdlib>
-#include <type_traits>
+// s2k_tile.hip -- host side of the tiled minimizer kernel: tile index, dispatch on l.  The kernel itself is in
+// s2k_tile_impl.h; this unit carries its run-time-l instantiation, s2k_tile_inst.hip the compile-time ones.
+#include "s2k_tile_impl.h"
 
 namespace s2k {
-namespace {
 
-constexpr int TW = 4;                                  // waves per block (they share the two seed tables)
-constexpr int HS_OFF = 16;                             // data starts here; byte HS_OFF-1 absorbs "slot -1" stores
-constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window slack
-constexpr int CAPP = 16;                               // positions per capture piece
-constexpr int NPC = TILE_T / CAPP;                     // 9 capture pieces per lane
-constexpr int MAX_L_TILED = 64;
-constexpr int LISTCAP = 512;                           // hits handled per dense batch
-constexpr int REG_LA = 2;
-constexpr int HPC_LA = 2;                              // seed look-ahead (positions) of the Hpc hash loop: 8 spills there
-constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
+#define S2K_DECL(LV)                                                                                                     \
+    hipError_t launch_tiles_static_##LV(bool hpc, hipStream_t st, const uint8_t *bases, const uint64_t *read_off,         \
+                                        uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles, const uint32_t *tile_read0, \
+                                        Sem sem, Records rec, uint64_t *pool_cursor, uint64_t *tile_rec_off,             \
+                                        uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts);
+S2K_STATIC_LS(S2K_DECL)
+#undef S2K_DECL
 
-struct HpcLds {
-    uint32_t fm[64][5];      // run-head flags of the lane's 144 raw bytes, 32-byte groups, bit 8b+d <-> byte 4d+b
-    uint32_t hbase[64];      // exclusive prefix of per-lane run-head counts
-    uint32_t halo_pos[64];   // tile-relative raw offsets of the run heads that follow the tile
-    uint8_t hl[64];          // raw lane that owns run head Tq*q (first head of hash lane q): search hint for the back-map
-};
-struct NoHpcLds {};
-
-template <bool HPC>
-struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
-    uint8_t buf[BUF_BYTES];
-    uint32_t caps[NPC][64];  // hash of the last hit of each 16-position piece
-    uint32_t hm[64][5];      // raw hit masks, bit x = lane-local hash position x (stored bytewise)
-    uint16_t list[LISTCAP];  // validated hits of the current batch, tile-local hash positions, ascending
-    uint16_t jobx[64];       // hits whose hash must be re-derived: tile-local position ...
-    uint32_t jobslot[64];    // ... and record slot (relative to the tile's base)
-    int32_t hb[64];          // read starts inside the tile, as hash-space positions (ascending)
-    uint64_t rs[64];         // rs[i] = read_off[r0 + i]
-};
-constexpr int TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c], l-1)};  OUT table at 2048: {rotl(h[c], l), rotr(rc[c], 1)}
-template <bool HPC>
-constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>); }
-static_assert(2 * block_lds_bytes<true>() <= 160 * 1024, "two blocks per CU must fit the 160 KiB LDS");
-
-// inclusive scan over the 64 lanes with DPP row shifts / broadcasts (no LDS round trips)
-__device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
-    (void)lane;
-    uint32_t t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
-    uint32_t a = v + t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
-    a += t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false); // row_shr:3
-    a += t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x114, 0xf, 0xe, false); // row_shr:4, banks 1-3
-    a += t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x118, 0xf, 0xc, false); // row_shr:8, banks 2-3
-    a += t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
-    a += t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
-    a += t;
-    return a;
-}
-// value of lane `src` (wave-uniform index) in every lane: v_readlane, no LDS round trip
-__device__ inline uint32_t bcast(uint32_t v, int src) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
-}
-
-// index of the n-th (0-based) set bit of w; n < popc(w)
-__device__ inline uint32_t select_nth_32(uint32_t w, uint32_t n) {
-    uint32_t r = 0, c;
-    c = __popc(w & 0xFFFFu); if (n >= c) { n -= c; r += 16; w >>= 16; }
-    c = __popc(w & 0xFFu);   if (n >= c) { n -= c; r += 8;  w >>= 8; }
-    c = __popc(w & 0xFu);    if (n >= c) { n -= c; r += 4;  w >>= 4; }
-    c = __popc(w & 0x3u);    if (n >= c) { n -= c; r += 2;  w >>= 2; }
-    c = w & 1u;              if (n >= c) { r += 1; }
-    return r;
-}
-// bit i of a byte -> bit 4i
-__device__ inline uint32_t spread4(uint32_t x) {
-    x = (x | (x << 12)) & 0x000F000Fu;
-    x = (x | (x << 6)) & 0x03030303u;
-    x = (x | (x << 3)) & 0x11111111u;
-    return x;
-}
-// flag-mask group (bit 8b+d <-> byte 4d+b) -> natural order (bit 4d+b)
-__device__ inline uint32_t untranspose(uint32_t u) {
-    return spread4(u & 0xFFu) | (spread4((u >> 8) & 0xFFu) << 1) | (spread4((u >> 16) & 0xFFu) << 2) |
-           (spread4(u >> 24) << 3);
-}
-// bits of a group mask that belong to bytes at or before (d, b) in byte order
-__host__ __device__ constexpr uint32_t at_or_before(int d, int b) {
-    uint32_t m = 0;
-    for (int bb = 0; bb < 4; bb++)
-        for (int dd = 0; dd < 8; dd++)
-            if (dd < d || (dd == d && bb <= b)) m |= 1u << (8 * bb + dd);
-    return m;
-}
-
-// Seed look-ups of the hot loop.  The two 2 KiB tables sit at LDS byte offsets 0 (IN pairs) and 2048 (OUT
-// pairs); the kernel has no static LDS, so the dynamic region starts at 0 (checked at kernel entry).  The byte
-// offset of a base's entries is formed ONCE, when the base enters the window, by one v_lshlrev_b32_sdwa (byte
-// select + x8); its IN pair is read right away and its OUT pair l positions later with the same offset
-// register and the table base in the ds_read immediate.  (Reading both pairs at once would be one LDS
-// instruction fewer, but the 4-register result tuple then stays pinned for ~40 positions: 256 VGPRs + spills.)
-template <int BYTE>
-__device__ __forceinline__ uint32_t byte_x8(uint32_t w) {
-    uint32_t off;
-    if constexpr (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(3u), "v"(w));
-    if constexpr (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(3u), "v"(w));
-    if constexpr (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(3u), "v"(w));
-    if constexpr (BYTE == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(3u), "v"(w));
-    return off;
-}
-template <int TABLE_OFF>
-__device__ __forceinline__ uint2 seed_pair(uint32_t off) { // ds_read_b64 v, off offset:TABLE_OFF
-    typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
-    const unsigned long long v = *reinterpret_cast<lds_cu64 *>(off + TABLE_OFF);
-    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-}
-__device__ __forceinline__ uint2 tab_in(const uint2 *tab, uint32_t c) { return tab[c]; }
-__device__ __forceinline__ uint2 tab_out(const uint2 *tab, uint32_t c) { return tab[256 + c]; }
-
-// ------------------------------------------------------------------------------------------------
-// Hash loop, compile-time l, NP 16-byte pieces per lane.  Lane q owns hash positions
-// [16*NP*q, 16*NP*(q+1)) of the byte array D (LDS).  Branch-free: per position
-//   hv = min(fh, rh); hit = hv <= bound; cap = hit ? hv : cap; bits = bits<<1 | hit; roll.
-// ------------------------------------------------------------------------------------------------
-// One position of the hot loop.  The hit test, the capture of the hit's hash and the hit bit are three
-// VALU instructions chained through VCC (compare -> select -> add-with-carry shifts the bit in).
-__device__ __forceinline__ void hit_track(uint32_t hv, uint32_t bound, uint32_t &cap, uint32_t &bits) {
-    asm("v_cmp_ge_u32_e32 vcc, %2, %3\n\t"
-        "v_cndmask_b32_e32 %0, %0, %3, vcc\n\t"
-        "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
-        : "+v"(cap), "+v"(bits)
-        : "s"(bound), "v"(hv)
-        : "vcc");
-}
-
-// Step s of the lane's stream (s = 0 .. T+L-1, all compile-time): base s enters the window; for s >= L the
-// l-mer at position p = s - L is complete, so it is tested and then rolled forward with OUT[p], IN[s].
-template <int L, int T, int LA, int S, class WL>
-__device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], uint32_t (&A)[T + L], uint2 (&EI)[T + L],
-                                           uint2 (&EO)[T], uint32_t &fh, uint32_t &rh, uint32_t &cap, uint32_t &bits,
-                                           uint32_t bound, uint8_t *hmb, WL &Sx, int lane) {
-    if constexpr (S < T + L - 1) {
-        // seeds are fetched 8 steps ahead of their use, a group of 8 at a time
-        if constexpr (S % LA == 0) {
-            constexpr int G = S + LA; // first base of the group entering LA steps from now
-            if constexpr (G % 16 == 0 && G > 0) { // the group starts a new 16-byte piece: slide the 32-byte window
-                W[0] = W[4]; W[1] = W[5]; W[2] = W[6]; W[3] = W[7];
-                const uint4 v = src[G / 16 + 1];
-                W[4] = v.x; W[5] = v.y; W[6] = v.z; W[7] = v.w;
-            }
-            constexpr int WB = (G % 16); // offset of the group inside the window
-#define S2K_IN(J)                                                          \
-    if constexpr (J < LA && G + J < T + L - 1) {                          \
-        A[G + J] = byte_x8<(WB + J) & 3>(W[(WB + J) >> 2]);                \
-        EI[G + J] = seed_pair<0>(A[G + J]);                                \
-    }
-            S2K_IN(0) S2K_IN(1) S2K_IN(2) S2K_IN(3) S2K_IN(4) S2K_IN(5) S2K_IN(6) S2K_IN(7)
-#undef S2K_IN
-            constexpr int H = S + LA - L; // first base of the group leaving LA steps from now
-#define S2K_OUT(J)                                                         \
-    if constexpr (J < LA && H + J >= 0 && H + J < T - 1) EO[H + J] = seed_pair<2048>(A[H + J]);
-            S2K_OUT(0) S2K_OUT(1) S2K_OUT(2) S2K_OUT(3) S2K_OUT(4) S2K_OUT(5) S2K_OUT(6) S2K_OUT(7)
-#undef S2K_OUT
-        }
-        if constexpr (S < L) { // warm-up: first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174)
-            fh = __builtin_rotateleft32(fh, 1) ^ EI[S].x;
-            rh = __builtin_rotateright32(rh, 1) ^ EI[S].y;
-        } else {
-            constexpr int P = S - L;
-            const uint32_t hv = fh < rh ? fh : rh;                              // canonical (src/nthash_hpc.rs:276)
-            hit_track(hv, bound, cap, bits);                                    // hv <= bound (src/nthash_hpc.rs:277 / src/lib.rs:228)
-            fh = __builtin_rotateleft32(fh, 1) ^ EO[P].x ^ EI[S].x;             // src/nthash_hpc.rs:245
-            rh = __builtin_rotateright32(rh, 1) ^ EO[P].y ^ EI[S].y;            // src/nthash_hpc.rs:247-249
-            if constexpr (P % 8 == 7) {
-                hmb[P / 8] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-                if constexpr (P % CAPP == CAPP - 1) Sx.caps[P / CAPP][lane] = cap;
-                bits = 0;
-            }
-        }
-        hash_steps<L, T, LA, S + 1>(src, W, A, EI, EO, fh, rh, cap, bits, bound, hmb, Sx, lane);
-    } else { // last position: test only, nothing left to roll into
-        const uint32_t hv = fh < rh ? fh : rh;
-        hit_track(hv, bound, cap, bits);
-        hmb[(T - 1) / 8] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-        Sx.caps[(T - 1) / CAPP][lane] = cap;
-    }
-}
-
-template <int L, int NP, int LA, class WL>
-__device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t bound, int lane, WL &S) {
-    constexpr int T = 16 * NP;
-    static_assert(L >= 9 && L <= 32, "the static schedule assumes 8 < l <= 32");
-    uint32_t W[8]; // 32-byte window over the lane's stream: pieces i, i+1
-    const uint4 *src = reinterpret_cast<const uint4 *>(D + T * lane);
-    {
-        const uint4 v0 = src[0], v1 = src[1];
-        W[0] = v0.x; W[1] = v0.y; W[2] = v0.z; W[3] = v0.w;
-        W[4] = v1.x; W[5] = v1.y; W[6] = v1.z; W[7] = v1.w;
-    }
-    uint32_t A[T + L];
-    uint2 EI[T + L], EO[T];
-    A[0] = byte_x8<0>(W[0]); A[1] = byte_x8<1>(W[0]); A[2] = byte_x8<2>(W[0]); A[3] = byte_x8<3>(W[0]);
-    if constexpr (LA > 4) { A[4] = byte_x8<0>(W[1]); A[5] = byte_x8<1>(W[1]); A[6] = byte_x8<2>(W[1]); A[7] = byte_x8<3>(W[1]); }
-#pragma unroll
-    for (int i = 0; i < LA; i++) EI[i] = seed_pair<0>(A[i]);
-    uint32_t fh = 0, rh = 0, cap = 0, bits = 0;
-    uint8_t *hmb = reinterpret_cast<uint8_t *>(S.hm[lane]);
-    hash_steps<L, T, LA, 0>(src, W, A, EI, EO, fh, rh, cap, bits, bound, hmb, S, lane);
-}
-
-// Same loop for a run-time l (1..64): bytes are fetched one by one from LDS.  Slower; only l values
-// without a static instantiation come here.
-template <class WL>
-__device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 *__restrict__ tab, uint32_t bound, int lane, WL &S,
-                                         uint32_t l, int np) {
-    const uint8_t *q = D + 16 * np * lane;
-    uint32_t fh = 0, rh = 0;
-    for (uint32_t i = 0; i < l; i++) {
-        uint2 ti = tab_in(tab, q[i]);
-        fh = __builtin_rotateleft32(fh, 1) ^ ti.x;
-        rh = __builtin_rotateright32(rh, 1) ^ ti.y;
-    }
-    uint32_t cap = 0, bits = 0;
-    uint8_t *hmb = reinterpret_cast<uint8_t *>(S.hm[lane]);
-    for (int pos = 0; pos < 16 * np; pos++) {
-        uint32_t hv = fh < rh ? fh : rh;
-        bool hit = hv <= bound;
-        cap = hit ? hv : cap;
-        bits = (bits << 1) | (hit ? 1u : 0u);
-        uint2 to = tab_out(tab, q[pos]);
-        uint2 ti = tab_in(tab, q[pos + l]);
-        fh = __builtin_rotateleft32(fh, 1) ^ to.x ^ ti.x;
-        rh = __builtin_rotateright32(rh, 1) ^ to.y ^ ti.y;
-        if ((pos & 7) == 7) {
-            hmb[pos >> 3] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-            if ((pos & (CAPP - 1)) == CAPP - 1) S.caps[pos / CAPP][lane] = cap;
-            bits = 0;
-        }
-    }
-}
-
-// Everything below is force-inlined into the kernel so that the LDS operands keep their address space
-// (a generic pointer costs a 64-bit add, a null compare and a select per table lookup).
-template <int L, bool HPC, class WL>
-__device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, uint32_t bound,
-                                           int lane, WL &S, uint32_t l, int np) {
-    if constexpr (L > 0) {
-        if constexpr (!HPC) {
-            hash_loop_static<L, 9, REG_LA>(D, bound, lane, S); // raw tiles always span 9 pieces per lane
-        } else {
-            switch (np) { // wave-uniform: the compacted tile is shorter than the raw one
-            case 1: hash_loop_static<L, 1, HPC_LA>(D, bound, lane, S); break;
-            case 3: hash_loop_static<L, 3, HPC_LA>(D, bound, lane, S); break;
-            case 5: hash_loop_static<L, 5, HPC_LA>(D, bound, lane, S); break;
-            case 7: hash_loop_static<L, 7, HPC_LA>(D, bound, lane, S); break;
-            default: hash_loop_static<L, 9, HPC_LA>(D, bound, lane, S); break;
-            }
-        }
-    } else {
-        hash_loop_dynamic(D, tab, bound, lane, S, l, np);
-    }
-}
-
-// Phase stamps (cycles per phase, kept in registers and flushed once per tile to one of 64 shards) exist only in
-// builds with -DS2K_PROFILE (tools/phases.sh): the 16 accumulators cost 32 VGPRs that production kernels need.
-#ifdef S2K_PROFILE
-#define S2K_STAMP(i)                                                                     \
-    do {                                                                                 \
-        if (sem.dbg_skip & 8) {                                                          \
-            uint64_t _n = __builtin_amdgcn_s_memtime();                                  \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
-            ph[i] += _n - stamp;                                                         \
-            stamp = _n;                                                                  \
-        }                                                                                \
-    } while (0)
-#else
-#define S2K_STAMP(i) do { (void)ph; (void)stamp; } while (0)
-#endif
-
-// ------------------------------------------------------------------------------------------------
-// Hpc pre-stage: in-place run-head compaction of the staged tile.  Returns R_t (run heads owned by
-// the tile) and leaves D[0..R_t) = head bytes, D[R_t..R_t+halo_n) = following heads, S.fm / S.hbase /
-// S.halo_pos for the back-map.  `na` accumulates bytes with bit 7 set.
-// ------------------------------------------------------------------------------------------------
-template <class WL>
-__device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t *__restrict__ bases,
-                                                const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
-                                                uint64_t t0, uint32_t tile_len, uint32_t r0, uint32_t r1, uint32_t l,
-                                                int lane, uint32_t &na, uint32_t &halo_n_out, uint64_t bpos0,
-                                                uint32_t prev_byte0, bool forced0, const Sem &sem, uint64_t *ph,
-                                                uint64_t &stamp) {
-    // 1. mark read starts strictly inside the tile (forced run heads: every read starts a new run,
-    //    src/nthash_hpc.rs:138-150 runs per read).  bpos0 = read_off[r0 + 1 + lane] was fetched ahead.
-    {
-        uint64_t sp = bpos0;
-        for (uint64_t c0 = 0;; c0 += 64) {
-            if (sp > t0 && sp < t0 + tile_len) {
-                uint32_t o = (uint32_t)(sp - t0);
-                atomicOr(reinterpret_cast<unsigned int *>(D + (o & ~3u)), 0x80u << (8 * (o & 3u)));
-            }
-            if ((uint64_t)r0 + 1 + c0 + 64 > (uint64_t)r1) break; // wave-uniform: all starts up to r1 covered
-            const uint64_t ri = (uint64_t)r0 + 1 + c0 + 64 + lane;
-            sp = ri <= n_reads ? read_off[ri] : ~0ull;
-        }
-    }
-    wave_sync();
-    S2K_STAMP(13); // compaction: read-start marks
-    // 2. lane chunk -> registers
-    uint32_t c[36];
-    const uint4 *src = reinterpret_cast<const uint4 *>(D + TILE_T * lane);
-#pragma unroll
-    for (int p = 0; p < 9; p++) {
-        uint4 v = src[p];
-        c[4 * p] = v.x; c[4 * p + 1] = v.y; c[4 * p + 2] = v.z; c[4 * p + 3] = v.w;
-    }
-    uint32_t prevw;
-    if (lane == 0) {
-        if (forced0) c[0] |= 0x80u; // the tile starts a read
-        prevw = prev_byte0 << 24;
-    } else {
-        prevw = (uint32_t)D[TILE_T * lane - 1] << 24;
-    }
-    const uint32_t last_raw = bcast(c[35] >> 24, 63); // last raw byte of a full tile
-    // the 128 staged look-ahead bytes serve the first round of the run-head search after the tile; read them
-    // before the buffer is compacted in place (lanes 0..31, 4 bytes each)
-    const uint32_t la_word = lane < 32 ? *reinterpret_cast<const uint32_t *>(D + TILE_BASES + 4 * lane) : 0u;
-    const int vb = (int)tile_len - TILE_T * lane;      // valid bytes in this lane's chunk (may be <=0 or >=144)
-    const bool partial = tile_len < (uint32_t)TILE_BASES;
-    // 3. pass 1: SWAR head flags -> transposed group masks + count
-    uint32_t fmk[5] = {0, 0, 0, 0, 0};
-#pragma unroll
-    for (int d = 0; d < 36; d++) {
-        uint32_t cur = c[d];
-        uint32_t prv = (cur << 8) | (prevw >> 24);
-        uint32_t x = (cur ^ prv) & 0x7F7F7F7Fu;
-        uint32_t t = ((x + 0x7F7F7F7Fu) | cur) & 0x80808080u; // bit7: differs from predecessor, or marked read start
-        if (partial) {
-            int v = vb - 4 * d;
-            uint32_t keep = v >= 4 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << (8 * v)) - 1u));
-            t &= keep;
-        }
-        fmk[d >> 3] |= t >> (7 - (d & 7));
-        prevw = cur;
-    }
-    uint32_t cnt = __popc(fmk[0]) + __popc(fmk[1]) + __popc(fmk[2]) + __popc(fmk[3]) + __popc(fmk[4]);
-    uint32_t incl = wave_incl_scan(cnt, lane);
-    uint32_t base = incl - cnt;
-    const uint32_t R = bcast(incl, 63);
-#pragma unroll
-    for (int g = 0; g < 5; g++) S.fm[lane][g] = fmk[g];
-    S.hbase[lane] = base;
-    { // hint table for the back-map: hl[q] = raw lane that owns run head Tq*q (first head of hash lane q).  Raw lane
-      // o owns heads [base, base+cnt), i.e. the hash-lane starts q with base <= Tq*q < base+cnt: at most a few.
-        const uint32_t need = (R + 1023u) >> 10;
-        const uint32_t tq = 16u * (need <= 1 ? 1u : need <= 3 ? 3u : need <= 5 ? 5u : need <= 7 ? 7u : 9u);
-        S.hl[lane] = 63; // hash lanes past the last head
-        wave_sync();
-        if (cnt) {
-            for (uint32_t q = (base + tq - 1) / tq; q * tq < base + cnt && q < 64; q++) S.hl[q] = (uint8_t)lane;
-        }
-    }
-    // all lanes hold their raw chunk in registers now -> the buffer may be overwritten in place
-    wave_sync();
-    S2K_STAMP(14); // compaction: chunk load + flags + scan
-    // 4. pass 2: every byte is stored at slot (#heads at or before it) - 1; bytes of one run carry the
-    //    same value, so only the slot matters.  Slot -1 of lane 0 lands on the scratch byte D[-1].
-    {
-        typedef __attribute__((address_space(3))) uint8_t lds_u8;
-        // LDS byte address of slot 0 minus one (so that "count of heads at or before" indexes directly)
-        uint32_t gaddr = (uint32_t)(uintptr_t)(lds_u8 *)D + base - 1;
-        auto pass2 = [&](auto partial_c) {
-            constexpr bool PARTIAL = decltype(partial_c)::value;
-#pragma unroll
-            for (int d = 0; d < 36; d++) {
-                const int g = d >> 3, dd = d & 7;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const uint32_t a = gaddr + __popc(fmk[g] & at_or_before(dd, b)); // v_and + v_bcnt(+gaddr)
-                    if (!PARTIAL || 4 * d + b < vb) *reinterpret_cast<lds_u8 *>(a) = (uint8_t)(c[d] >> (8 * b));
-                }
-                if (dd == 7) gaddr += __popc(fmk[g]);
-            }
-        };
-        // full tiles (all but the last of the stream) take the branch-free instantiation
-        if (partial) pass2(std::true_type{});
-        else pass2(std::false_type{});
-    }
-    S2K_STAMP(15); // compaction: byte stores
-    // 5. run heads that follow the tile: up to l of them (hash needs l-1, the end position one more)
-    uint32_t halo_n = 0;
-    if (!partial) {
-        uint64_t q = t0 + TILE_BASES;
-        uint32_t pb = last_raw;
-        bool first = true;
-        while (halo_n < l && q < n_bases) { // wave-uniform
-            const uint32_t span = first ? 128u : 256u; // bytes examined this round
-            uint64_t a = q + 4 * (uint64_t)lane;
-            int nval = (a >= n_bases || 4u * (uint32_t)lane >= span) ? 0 : (n_bases - a >= 4 ? 4 : (int)(n_bases - a));
-            uint32_t wv = 0;
-            if (first) {
-                wv = la_word; // bytes past the end of the stream were staged as zeros and are masked by nval
-            } else {
-                if (nval == 4) wv = *reinterpret_cast<const uint32_t *>(bases + a);
-                else
-                    for (int b = 0; b < nval; b++) wv |= (uint32_t)bases[a + b] << (8 * b);
-            }
-            na |= wv & (nval >= 4 ? 0x80808080u : (nval <= 0 ? 0u : (0x80808080u & ((1u << (8 * nval)) - 1u))));
-            uint32_t pw = __shfl_up(wv, 1);
-            if (lane == 0) pw = pb << 24;
-            uint32_t prv = (wv << 8) | (pw >> 24);
-            uint32_t x = (wv ^ prv) & 0x7F7F7F7Fu;
-            uint32_t t = (x + 0x7F7F7F7Fu) & 0x80808080u;
-            t &= nval >= 4 ? 0xFFFFFFFFu : (nval <= 0 ? 0u : ((1u << (8 * nval)) - 1u));
-            uint32_t cn = __popc(t);
-            uint32_t in2 = wave_incl_scan(cn, lane);
-            uint32_t idx = halo_n + in2 - cn;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                if (t & (0x80u << (8 * b))) {
-                    if (idx < l) {
-                        D[R + idx] = (uint8_t)(wv >> (8 * b));
-                        S.halo_pos[idx] = (uint32_t)(a - t0) + b;
-                    }
-                    idx++;
-                }
-            }
-            halo_n += bcast(in2, 63);
-            pb = bcast(wv >> 24, first ? 31 : 63);
-            q += span;
-            first = false;
-        }
-        if (halo_n > l) halo_n = l;
-    }
-    halo_n_out = halo_n;
-    wave_sync();
-    return R;
-}
-
-// Back-map of one Hpc hit: tile-relative raw offsets of run heads x and x + l (x < R; x + l may be one of the
-// run heads that follow the tile).  The owner raw lane of a head is the last o with hbase[o] <= head; S.hl
-// brackets it to the raw lanes spanned by the head's hash lane.  Written so that the LDS reads of the two
-// look-ups are independent and can be in flight together (a chain of ~10 dependent reads per look-up cost
-// ~3.4k cycles per round of 64 hits).
-template <class WL>
-__device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l, uint32_t R, uint32_t halo_n,
-                                            uint32_t Tq, uint32_t rcpTq, uint32_t &raw_x, uint32_t &raw_e) {
-    const uint32_t y = x + l;
-    const bool y_in = y < R;
-    const uint32_t yy = y_in ? y : x; // look-up 2 degenerates to look-up 1 when x + l lies after the tile
-    (void)Tq;
-    const uint32_t q1 = __umulhi(x, rcpTq), q2 = __umulhi(yy, rcpTq);
-    uint32_t lo1 = S.hl[q1], hi1 = q1 < 63 ? S.hl[q1 + 1] : 63u;
-    uint32_t lo2 = S.hl[q2], hi2 = q2 < 63 ? S.hl[q2 + 1] : 63u;
-    // three candidates beyond lo at once; a wider bracket (long homopolymers: raw lanes without heads) loops
-    {
-        const uint32_t a1 = S.hbase[lo1 + 1 > 63 ? 63 : lo1 + 1], a2 = S.hbase[lo1 + 2 > 63 ? 63 : lo1 + 2], a3 = S.hbase[lo1 + 3 > 63 ? 63 : lo1 + 3];
-        const uint32_t b1 = S.hbase[lo2 + 1 > 63 ? 63 : lo2 + 1], b2 = S.hbase[lo2 + 2 > 63 ? 63 : lo2 + 2], b3 = S.hbase[lo2 + 3 > 63 ? 63 : lo2 + 3];
-        uint32_t o1 = lo1 + (uint32_t)(lo1 + 1 <= hi1 && a1 <= x) + (uint32_t)(lo1 + 2 <= hi1 && a2 <= x) + (uint32_t)(lo1 + 3 <= hi1 && a3 <= x);
-        uint32_t o2 = lo2 + (uint32_t)(lo2 + 1 <= hi2 && b1 <= yy) + (uint32_t)(lo2 + 2 <= hi2 && b2 <= yy) + (uint32_t)(lo2 + 3 <= hi2 && b3 <= yy);
-        while (o1 == lo1 + 3 && o1 < hi1 && S.hbase[o1 + 1] <= x) o1++, lo1++;
-        while (o2 == lo2 + 3 && o2 < hi2 && S.hbase[o2 + 1] <= yy) o2++, lo2++;
-        lo1 = o1;
-        lo2 = o2;
-    }
-    const uint32_t n1 = x - S.hbase[lo1], n2 = yy - S.hbase[lo2];
-    uint32_t w1[5], w2[5];
-#pragma unroll
-    for (int d = 0; d < 5; d++) {
-        w1[d] = S.fm[lo1][d];
-        w2[d] = S.fm[lo2][d];
-    }
-    auto decode = [](const uint32_t (&w)[5], uint32_t n) {
-        uint32_t g = 0, word = w[0];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const uint32_t c = __popc(word);
-            if (n >= c && g == (uint32_t)d) {
-                n -= c;
-                g++;
-                word = w[d + 1];
-            }
-        }
-        return 32 * g + select_nth_32(untranspose(word), n);
-    };
-    raw_x = TILE_T * lo1 + decode(w1, n1);
-    const uint32_t hx = y - R; // only meaningful when !y_in; validated hits guarantee hx < halo_n
-    const uint32_t he = S.halo_pos[(!y_in && hx < halo_n) ? hx : 0];
-    raw_e = y_in ? TILE_T * lo2 + decode(w2, n2) : he;
-}
-
-// Dense phase of one tile: hit bitmasks -> validated, ordered minimizer records.  Returns the number of
-// records (tile_cnt) and sets `base` (tile_rec_off).  See the file header for the idea.
-template <int L, bool HPC, class WL>
-__device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const uint2 *tab,
-                                                const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t t,
-                                                uint64_t t0, uint32_t tile_len, uint32_t nh, uint32_t halo_n,
-                                                uint32_t Tq, uint32_t l, uint32_t r0, uint32_t r1, uint64_t bpos0,
-                                                uint64_t rs0, int lane, const Records &rec, uint64_t *pool_cursor,
-                                                uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem, uint64_t *ph,
-                                                uint64_t &stamp) {
-    // (1) read starts that matter for this tile -> hash-space boundaries HB; an l-mer x is invalid iff
-    //     some boundary has HB - w <= x <= HB - 1  (w = l-1 raw positions for Regular: the l-mer must end
-    //     before the next read, src/lib.rs:215-230; w = l run heads for Hpc: head x+l must exist in the
-    //     same read, src/nthash_hpc.rs:265-267).  The first read start at or after the tile end (or the
-    //     end of the stream) is the one external boundary.
-    const uint32_t wclr = HPC ? l : l - 1;
-    const uint32_t rcpTq = 0xFFFFFFFFu / Tq + 1u; // x / Tq == umulhi(x, rcpTq) for x < 2^16 (Tq <= 144)
-    uint32_t vm[5]; // validated hit mask of this lane
-    {
-        int vc = (int)nh - (int)(Tq * lane); // hash positions of this lane that exist
-#pragma unroll
-        for (int d = 0; d < 5; d++) {
-            int v = vc - 32 * d;
-            uint32_t keep = v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
-            vm[d] = S.hm[lane][d] & keep;
-        }
-    }
-    const uint64_t tile_end = t0 + tile_len;
-    uint32_t nb = 0;                  // internal boundaries (reads r0+1 .. r0+nb start inside the tile)
-    const bool many = (r1 - r0) > 62; // more read starts than the LDS lists hold: generic per-hit lookups
-    if (lane == 0) S.rs[0] = rs0;
-    {
-        uint64_t bpos = bpos0; // read_off[r0 + 1 + lane], fetched ahead; later chunks are loaded here (rare)
-        uint64_t chunk_prev = rs0; // start of the read whose end lane 0 holds
-        for (uint32_t c0 = 0;; c0 += 64) { // wave-uniform; one trip unless the tile holds > 63 read starts
-            const bool internal = bpos > t0 && bpos < tile_end;
-            const bool external = bpos >= tile_end; // entry n_reads (end of stream) always qualifies
-            const uint64_t em = __ballot(external);
-            const int first_ext = em ? __builtin_ctzll(em) : 64;
-            int32_t HB = 0x7FFFFFFF;
-            if (internal || (external && lane == first_ext)) {
-                if constexpr (HPC) {
-                    if (bpos < tile_end) { // rank of the forced run head at raw offset bpos - t0
-                        const uint32_t rel = (uint32_t)(bpos - t0), o = rel / TILE_T, wi = rel % TILE_T;
-                        const uint32_t g = wi >> 5, pi = wi & 31, d = pi >> 2, bb = pi & 3;
-                        const uint32_t before = (((1u << d) - 1u) * 0x01010101u) | ((0x01010101u << d) & ((1u << (8 * bb)) - 1u));
-                        uint32_t c = S.hbase[o];
-                        for (uint32_t gg = 0; gg < g; gg++) c += __popc(S.fm[o][gg]);
-                        c += __popc(S.fm[o][g] & before);
-                        HB = (int32_t)c;
-                    } else { // first read start (or stream end) after the tile: count the run heads before it
-                        HB = -1; // resolved below by the whole wave
-                    }
-                } else {
-                    const uint64_t rel = bpos - t0;
-                    HB = rel > 0x3FFFFFFFull ? 0x3FFFFFFF : (int32_t)rel;
-                }
-            }
-            if constexpr (HPC) {
-                if (em) { // first read start (or stream end) at/after the tile end: run heads before it, counted by all lanes
-                    const uint64_t eb = ((uint64_t)bcast((uint32_t)(bpos >> 32), first_ext) << 32) | bcast((uint32_t)bpos, first_ext);
-                    if (eb >= tile_end) {
-                        const uint64_t relb = eb - t0;
-                        const bool before = (uint32_t)lane < halo_n && (uint64_t)S.halo_pos[lane] < relb;
-                        const int32_t hbx = (int32_t)(nh + (uint32_t)__popcll(__ballot(before)));
-                        if (lane == first_ext) HB = hbx;
-                    }
-                }
-            }
-            // every lane clears [HB - w, HB - 1] for each boundary of this chunk
-            uint64_t todo = __ballot(internal) | (em ? (1ull << first_ext) : 0ull);
-            while (todo) {
-                const int z = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const int32_t hbz = (int32_t)bcast((uint32_t)HB, z);
-                const int lo = hbz - (int)wclr - (int)(Tq * lane), hi = hbz - 1 - (int)(Tq * lane); // lane-local, inclusive
-                if (hi >= 0 && lo < (int)Tq) {
-#pragma unroll
-                    for (int d = 0; d < 5; d++) {
-                        const int a = lo - 32 * d, bnd = hi - 32 * d;
-                        if (bnd >= 0 && a < 32) {
-                            const uint32_t m_hi = bnd >= 31 ? 0xFFFFFFFFu : ((2u << bnd) - 1u);
-                            const uint32_t m_lo = a <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << a);
-                            vm[d] &= ~(m_hi & m_lo);
-                        }
-                    }
-                }
-            }
-            if constexpr (!HPC) {
-                // A read of exactly l bases has one l-mer that fits, but the reference yields nothing unless
-                // seq.len() > l (src/lib.rs:97): clear that position.  Lane i holds the END of read r0+c0+i
-                // (= start of the next one); its start is the previous lane's value (rs0 / the previous chunk's
-                // last value for lane 0).
-                uint64_t pstart = ((uint64_t)__shfl_up((uint32_t)(bpos >> 32), 1) << 32) | __shfl_up((uint32_t)bpos, 1);
-                if (lane == 0) pstart = chunk_prev;
-                const bool exact = bpos != ~0ull && bpos - pstart == (uint64_t)l && pstart >= t0 && pstart < tile_end;
-                uint64_t ex = __ballot(exact);
-                while (ex) {
-                    const int z = __builtin_ctzll(ex);
-                    ex &= ex - 1;
-                    const uint32_t hx = bcast((uint32_t)(pstart - t0), z); // tile-local position of that read's only l-mer
-                    const int rel = (int)hx - (int)(Tq * lane);
-                    if (rel >= 0 && rel < (int)Tq) {
-#pragma unroll
-                        for (int d = 0; d < 5; d++) // static indices: vm[] must stay in registers
-                            if ((rel >> 5) == d) vm[d] &= ~(1u << (rel & 31));
-                    }
-                }
-                chunk_prev = ((uint64_t)bcast((uint32_t)(bpos >> 32), 63) << 32) | bcast((uint32_t)bpos, 63);
-            }
-            if (!many && internal && c0 + lane < 63) { // remembered for the per-hit read lookup
-                S.hb[c0 + lane] = HB;
-                S.rs[c0 + lane + 1] = bpos;
-            }
-            nb += (uint32_t)__popcll(__ballot(internal));
-            if (em) break;
-            const uint64_t ri = (uint64_t)r0 + 1 + c0 + 64 + lane;
-            bpos = ri <= n_reads ? read_off[ri] : ~0ull;
-        }
-    }
-    S2K_STAMP(3); // boundaries
-    // (2) per-lane counts -> offsets
-    const uint32_t cnt = __popc(vm[0]) + __popc(vm[1]) + __popc(vm[2]) + __popc(vm[3]) + __popc(vm[4]);
-    const uint32_t incl = wave_incl_scan(cnt, lane);
-    const uint32_t myoff = incl - cnt;
-    const uint32_t N = bcast(incl, 63); // valid minimizers of this tile
-    base = t * rec.slab_cap;
-    if (N == 0) return 0;
-    if (N > rec.slab_cap) { // rare: more hits than the per-tile slab holds
-        uint64_t got = 0;
-        if (lane == 0) got = atomicAdd((unsigned long long *)pool_cursor, (unsigned long long)N);
-        got = ((uint64_t)bcast((uint32_t)(got >> 32), 0) << 32) | bcast((uint32_t)got, 0);
-        base = rec.ovf_base + got;
-        if (base + N > rec.capacity) { // overflow region exhausted: the host re-runs with pool_needed
-            if (lane == 0) {
-                counts->pool_overflow = 1;
-                atomicMax((unsigned long long *)&counts->pool_needed, (unsigned long long)(got + N));
-            }
-            base = 0;
-            return 0;
-        }
-    }
-    // per-read minimizer counts, once per tile: read r0+i owns the hits in [HB[i-1], HB[i])
-    if (!many) {
-        uint32_t below_prev = 0, mine = 0;
-        for (uint32_t i = 0; i <= nb; i++) { // wave-uniform trip count
-            uint32_t below = N;
-            if (i < nb) {
-                const int lim = S.hb[i] - (int)(Tq * lane); // lane-local bits [0, lim) lie below boundary i
-                uint32_t c = 0;
-#pragma unroll
-                for (int d = 0; d < 5; d++) {
-                    const int v = lim - 32 * d;
-                    const uint32_t keep = v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
-                    c += __popc(vm[d] & keep);
-                }
-                below = bcast(wave_incl_scan(c, lane), 63);
-            }
-            if ((uint32_t)lane == i) mine = below - below_prev;
-            below_prev = below;
-        }
-        if ((uint32_t)lane <= nb && mine) atomicAdd(&mn_cnt[r0 + lane], mine);
-    }
-    uint32_t njobs = 0;
-    auto flush_jobs = [&]() {
-        wave_sync();
-        if ((uint32_t)lane < njobs) {
-            const uint8_t *q = D + S.jobx[lane];
-            uint32_t f = 0, r = 0;
-            if constexpr (L > 0) { // all byte reads first, then all seed reads: two LDS round trips in total
-                uint32_t by[L];
-#pragma unroll
-                for (int i = 0; i < L; i++) by[i] = q[i];
-                uint2 ti[L];
-#pragma unroll
-                for (int i = 0; i < L; i++) ti[i] = tab_in(tab, by[i]); // IN pair = {h[c], rotl(rc[c], l-1)}
-#pragma unroll
-                for (int i = 0; i < L; i++) {
-                    f ^= rotl32(ti[i].x, L - 1 - i);
-                    r ^= rotr32(ti[i].y, L - 1 - i);
-                }
-            } else {
-                for (uint32_t i = 0; i < l; i++) {
-                    const uint2 ti = tab_in(tab, q[i]);
-                    f ^= rotl32(ti.x, l - 1 - i);
-                    r ^= rotr32(ti.y, l - 1 - i);
-                }
-            }
-            rec.hash[base + S.jobslot[lane]] = f < r ? f : r;
-        }
-        njobs = 0;
-        wave_sync();
-    };
-    // (3) batches of up to LISTCAP hits: lanes list their own hits (ascending), then every lane takes one hit.
-    //     No global LOADS in here: a load would make the compiler drain the previous round's stores.
-    for (uint32_t b0 = 0; b0 < N; b0 += LISTCAP) {
-        wave_sync();
-        {
-            uint32_t k = myoff;
-#pragma unroll
-            for (int d = 0; d < 5; d++) {
-                uint32_t wv = vm[d];
-                while (wv) {
-                    const uint32_t bit = __builtin_ctz(wv);
-                    wv &= wv - 1;
-                    if (k >= b0 && k < b0 + LISTCAP) S.list[k - b0] = (uint16_t)(Tq * lane + 32 * d + bit);
-                    k++;
-                }
-            }
-        }
-        wave_sync();
-        S2K_STAMP(4); // scan + list
-        const uint32_t bn = N - b0 < (uint32_t)LISTCAP ? N - b0 : (uint32_t)LISTCAP;
-        auto rounds = [&](auto many_c) {
-        constexpr bool MANY = decltype(many_c)::value;
-        constexpr int U = 2; // hits per lane per iteration: the LDS round trips of the two overlap
-        for (uint32_t k0 = 0; k0 < bn; k0 += 64 * U) {
-            uint32_t kk[U], x[U], hv[U], rid[U];
-            bool act[U], need_re[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                kk[u] = k0 + 64 * u + lane;
-                act[u] = kk[u] < bn;
-                x[u] = hv[u] = rid[u] = 0;
-                need_re[u] = false;
-                if (act[u]) {
-                    x[u] = S.list[kk[u]];
-                    const uint32_t o = __umulhi(x[u], rcpTq), bit = x[u] - o * Tq, piece = bit / CAPP; // o = x / Tq
-                    const uint32_t pbits = reinterpret_cast<const uint16_t *>(S.hm[o])[piece]; // hits of the piece, bit j <-> position j
-                    // the kept hash belongs to the piece's last raw hit; pieces cut by nh may hold a stale one
-                    need_re[u] = (pbits >> ((bit & (CAPP - 1)) + 1)) != 0 || (Tq * o + CAPP * piece + CAPP > nh);
-                    hv[u] = S.caps[piece][o];
-                }
-            }
-            // hits that were not the last raw hit of their piece (~7 %) have no kept hash: queue them; one lane
-            // per queued hit re-derives it from the l bytes (closed form, src/nthash_hpc.rs:144,168)
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                uint64_t jobs = __ballot(need_re[u]);
-#ifdef S2K_PROFILE
-                if (sem.dbg_skip & 8) ph[7] += (uint64_t)__popcll(jobs);
-#endif
-                if (sem.dbg_skip & 64) jobs = 0;
-                if (jobs) {
-                    const uint32_t nj = (uint32_t)__popcll(jobs);
-                    if (njobs + nj > 64) flush_jobs(); // wave-uniform
-                    if (need_re[u]) {
-                        const uint32_t q = njobs + (uint32_t)__popcll(jobs & ((1ull << lane) - 1ull));
-                        S.jobx[q] = (uint16_t)x[u];
-                        S.jobslot[q] = b0 + kk[u];
-                    }
-                    njobs += nj;
-                }
-            }
-            S2K_STAMP(8); // round: list read, kept hash, job queueing
-            uint64_t p[U], e1[U]; // stream position of the l-mer start; position of the last base that belongs to it
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                p[u] = e1[u] = 0;
-                if (act[u]) {
-                    if constexpr (HPC) {
-                        uint32_t rp = 0, re = 0;
-                        hpc_rawpos2(S, x[u], l, nh, halo_n, Tq, rcpTq, rp, re); // head x + l exists: the hit survived validation
-                        p[u] = t0 + rp;
-                        e1[u] = t0 + re - 1; // st[p+l] - 1, src/nthash_hpc.rs:281
-                    } else {
-                        p[u] = t0 + x[u];
-                        e1[u] = p[u] + l - 1; // src/lib.rs:226
-                    }
-                }
-            }
-            S2K_STAMP(9); // round: back-map
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (act[u]) {
-                    uint64_t rstart;
-                    if constexpr (!MANY) {
-                        uint32_t c = 0;
-                        for (uint32_t i = 0; i < nb; i++) c += (S.hb[i] <= (int32_t)x[u]); // wave-uniform trip count, LDS broadcast
-                        rid[u] = r0 + c;
-                        rstart = S.rs[c];
-                    } else { // > 62 reads start in this tile: search the read table itself
-                        uint32_t lo = r0, hi = r1;
-                        while (lo < hi) {
-                            uint32_t mid = lo + (hi - lo + 1) / 2;
-                            if (read_off[mid] <= p[u]) lo = mid;
-                            else hi = mid - 1;
-                        }
-                        rid[u] = lo;
-                        rstart = read_off[lo];
-                    }
-                    const uint64_t slot = base + b0 + kk[u];
-                    if (!(sem.dbg_skip & 16)) {
-                        rec.j[slot] = (uint32_t)(p[u] - rstart);
-                        rec.jend[slot] = (uint32_t)(e1[u] - rstart);
-                        if (!need_re[u]) rec.hash[slot] = hv[u];
-                        rec.rid[slot] = rid[u];
-                    }
-                }
-            }
-            S2K_STAMP(10); // round: read lookup + stores
-            if constexpr (MANY) { // per-read minimizer counts: one atomic per (round, read); the common case is counted per tile above
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    uint64_t remm = __ballot(act[u]);
-                    while (remm) {
-                        const int z = __builtin_ctzll(remm);
-                        const uint32_t rz = bcast(rid[u], z);
-                        const uint64_t same = __ballot(act[u] && rid[u] == rz);
-                        if (lane == z) atomicAdd(&mn_cnt[rz], (uint32_t)__popcll(same));
-                        remm &= ~same;
-                    }
-                }
-            }
-        }
-        };
-        // > 62 reads starting in one tile take the variant that searches the read table itself; keeping it a
-        // separate instantiation keeps its global loads out of the common loop
-        if (many) rounds(std::true_type{});
-        else rounds(std::false_type{});
-    }
-    if (njobs) flush_jobs();
-    S2K_STAMP(12); // hash re-derivation
-    return N;
-}
-
-// Persistent kernel: every wave walks tiles t = wave_id, wave_id + n_waves, ...  While a tile is being
-// hashed, the next tile's 9344 bytes are already in flight into registers (NPRE x 16 B per lane), and the
-// read-table entries of the current tile are fetched before they are needed, so no global-load latency
-// sits on the critical path except in the first iteration.
-template <int L, bool HPC>
-__global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
-    const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
-    uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
-    uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    using WL = WaveLdsT<HPC>;
-    uint2 *tab = reinterpret_cast<uint2 *>(smem);
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap(); // lut() assumes it
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t l = L > 0 ? (uint32_t)L : sem.l;
-    for (int c = threadIdx.x; c < 256; c += 64 * TW) {
-        // Hpc tiles carry read-start marks in bit 7 (input is 7-bit there), so the table ignores it
-        uint32_t cc = HPC ? (c & 0x7F) : c;
-        uint32_t h = seed_h_scalar(cc), r = seed_rc_scalar(cc);
-        tab[c] = make_uint2(h, rotl32(r, l - 1));
-        tab[256 + c] = make_uint2(rotl32(h, l), rotr32(r, 1));
-    }
-    __syncthreads(); // the only workgroup barrier; waves are independent from here on
-    WL &S = *reinterpret_cast<WL *>(smem + TABLE_BYTES + (size_t)w * sizeof(WL));
-    uint8_t *D = S.buf + HS_OFF;
-    const uint64_t n_waves = (uint64_t)gridDim.x * TW;
-    uint64_t t = (uint64_t)blockIdx.x * TW + w;
-    if (t >= n_tiles) return;
-    uint64_t stamp = __builtin_amdgcn_s_memtime();
-    uint64_t ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-    // a tile is "full" when the tile and its 128 B look-ahead lie inside the stream: staged branch-free
-    auto is_full = [&](uint64_t tt) { return (tt + 1) * (uint64_t)TILE_BASES + 128 <= n_bases; };
-    // Software pipeline over this wave's tiles (cur = t, nxt = t + n_waves, nn = t + 2 n_waves):
-    //   pre[], prevb      : bases of nxt, issued while cur is hashed
-    //   r0n, r1n          : tile_read0 of nxt   (issued one iteration earlier, so their values are usable ...)
-    //   bposn, rs0n       : read_off[r0n + 1 + lane], read_off[r0n]   (... to address these, issued with pre[])
-    //   r0nn, r1nn        : tile_read0 of nn
-    // so no dependent global load is waited for on the spot after the prologue.
-    uint4 pre[NPRE];
-    uint32_t prevb = 0;
-    bool have_pre = false;
-    auto prefetch = [&](uint64_t tt) { // issue the loads for tile tt; nothing waits here
-        const uint8_t *g = bases + tt * (uint64_t)TILE_BASES;
-#pragma unroll
-        for (int r = 0; r < NPRE; r++) {
-            const uint32_t off = 16 * lane + 1024 * r;
-            pre[r] = (r < NPRE - 1 || lane < 8) ? *reinterpret_cast<const uint4 *>(g + off) : make_uint4(0, 0, 0, 0);
-        }
-        prevb = tt > 0 ? (uint32_t)g[-1] : 0u;
-    };
-    auto read_entries = [&](uint32_t rr0, uint64_t &bp, uint64_t &rs) {
-        const uint64_t bri = (uint64_t)rr0 + 1 + lane;
-        bp = bri <= n_reads ? read_off[bri] : ~0ull; // entry n_reads is the end of the stream
-        rs = read_off[rr0];
-    };
-    uint32_t r0 = tile_read0[t], r1 = tile_read0[t + 1];
-    uint64_t bpos0, rs0;
-    read_entries(r0, bpos0, rs0);
-    if (is_full(t)) {
-        prefetch(t);
-        have_pre = true;
-    }
-    uint32_t r0n = 0, r1n = 0;
-    if (t + n_waves < n_tiles) {
-        r0n = tile_read0[t + n_waves];
-        r1n = tile_read0[t + n_waves + 1];
-    }
-
-    for (; t < n_tiles; t += n_waves) {
-        const uint64_t t0 = t * (uint64_t)TILE_BASES;
-        const uint64_t rem = n_bases - t0;
-        const uint32_t avail = rem > (uint64_t)(TILE_BASES + 128) ? (uint32_t)(TILE_BASES + 128) : (uint32_t)rem;
-        const uint32_t tile_len = rem > (uint64_t)TILE_BASES ? (uint32_t)TILE_BASES : (uint32_t)rem;
-        uint32_t na = 0;
-        // ---- stage the tile (+128 B look-ahead) in LDS: 1 KiB per wave-instruction ----------------------
-        if (have_pre) {
-#pragma unroll
-            for (int r = 0; r < NPRE; r++) {
-                const uint32_t off = 16 * lane + 1024 * r;
-                if (r < NPRE - 1) na |= (pre[r].x | pre[r].y | pre[r].z | pre[r].w);
-                if (r < NPRE - 1 || lane < 8) *reinterpret_cast<uint4 *>(D + off) = pre[r];
-            }
-        } else { // tile at the end of the stream: guarded loads, zero past the end
-            const uint8_t *g = bases + t0;
-            for (int r = 0; r < NPRE; r++) {
-                const uint32_t off = 16 * lane + 1024 * r;
-                if (r == NPRE - 1 && lane >= 8) break;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (off + 16 <= avail) {
-                    v = *reinterpret_cast<const uint4 *>(g + off);
-                } else if (off < avail) {
-                    uint32_t tmp[4] = {0, 0, 0, 0};
-                    for (uint32_t b = 0; off + b < avail && b < 16; b++) tmp[b >> 2] |= (uint32_t)g[off + b] << (8 * (b & 3));
-                    v = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
-                }
-                if (r < NPRE - 1) na |= (v.x | v.y | v.z | v.w);
-                *reinterpret_cast<uint4 *>(D + off) = v;
-            }
-            prevb = t0 > 0 ? (uint32_t)bases[t0 - 1] : 0u;
-        }
-        const uint32_t cr0 = r0, cr1 = r1, cprev = prevb; // this tile's values (the registers get reused below)
-        if (lane == 0) S.buf[HS_OFF - 1] = 0;
-#pragma unroll
-        for (int g2 = 0; g2 < 5; g2++) S.hm[lane][g2] = 0;
-        wave_sync();
-        S2K_STAMP(0); // staging
-
-        uint32_t nh = tile_len; // number of hash positions owned by this tile
-        uint32_t halo_n = 0;
-        int np = 9;
-        if constexpr (HPC) {
-            if (!(sem.dbg_skip & 4))
-                nh = hpc_compact(D, S, bases, read_off, n_reads, n_bases, t0, tile_len, cr0, cr1, l, lane, na, halo_n, bpos0,
-                                 cprev, t0 == 0 || rs0 == t0, sem, ph, stamp);
-            if (__any((na & 0x80808080u) != 0)) { // bytes >= 0x80: the exact path is the serial kernel
-                if (lane == 0) counts->non_ascii = 1;
-            }
-            int need = (int)((nh + 1023) >> 10);
-            np = need <= 1 ? 1 : need <= 3 ? 3 : need <= 5 ? 5 : need <= 7 ? 7 : 9;
-        }
-        S2K_STAMP(1); // hpc compaction
-        // ---- next tile's loads: issued before the hash loop (Regular: their latency hides under it) or right
-        //      after it (Hpc: 40 staging registers live across the hash loop spill there; the dense phase covers
-        //      most of the latency instead) -----------------------------------------------------------------------
-        uint64_t bposn = ~0ull, rs0n = 0;
-        uint32_t r0nn = 0, r1nn = 0;
-        auto issue_next = [&]() {
-            have_pre = false;
-            if (t + n_waves < n_tiles) {
-                if (is_full(t + n_waves)) {
-                    prefetch(t + n_waves);
-                    have_pre = true;
-                }
-                read_entries(r0n, bposn, rs0n);
-                if (t + 2 * n_waves < n_tiles) {
-                    r0nn = tile_read0[t + 2 * n_waves];
-                    r1nn = tile_read0[t + 2 * n_waves + 1];
-                }
-            }
-        };
-        if constexpr (!HPC) issue_next();
-        const uint32_t Tq = 16 * np;
-        uint32_t N = 0;
-        uint64_t base = 0;
-        if (nh != 0 && sem.enabled) {
-            // ---- the hot loop ------------------------------------------------------------------------------
-            if (!(sem.dbg_skip & 1)) hash_stage<L, HPC>(D, tab, sem.bound_le, lane, S, l, np);
-            wave_sync();
-            S2K_STAMP(2); // hash loop
-        }
-        if constexpr (HPC) issue_next();
-        if (nh != 0 && sem.enabled) {
-            if (!(sem.dbg_skip & 2))
-                N = dense_phase<L, HPC>(S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
-                                     rs0, lane, rec, pool_cursor, mn_cnt, counts, base, sem, ph, stamp);
-            S2K_STAMP(5); // rounds
-        }
-        if (lane == 0) {
-            tile_cnt[t] = N;
-            tile_rec_off[t] = base;
-        }
-        wave_sync(); // LDS of this wave is reused by the next tile
-        r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; // rotate the pipeline
-        S2K_STAMP(6); // tail
-    }
-#ifdef S2K_PROFILE
-    if ((sem.dbg_skip & 8) && lane == 0)
-        for (int i = 0; i < 16; i++) atomicAdd((unsigned long long *)&counts->dbg_cycles[blockIdx.x & 63][i], (unsigned long long)ph[i]);
-#endif
-}
-
-// tile_read0[t] = last read index r (0 <= r < n_reads) with read_off[r] <= min(t*TILE, n_bases)
-__global__ __launch_bounds__(256) void tile_index_kernel(const uint64_t *__restrict__ read_off, uint64_t n_reads,
-                                                         uint64_t n_bases, uint64_t n_tiles,
-                                                         uint32_t *__restrict__ tile_read0) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > n_tiles) return;
-    uint64_t pos = t * (uint64_t)TILE_BASES;
-    if (pos > n_bases) pos = n_bases;
-    uint64_t lo = 0, hi = n_reads - 1;
-    while (lo < hi) {
-        uint64_t mid = lo + (hi - lo + 1) / 2;
-        if (read_off[mid] <= pos) lo = mid;
-        else hi = mid - 1;
-    }
-    tile_read0[t] = (uint32_t)lo;
-}
-
-template <int L, bool HPC>
-hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
-                           uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
-                           uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts) {
-    auto kern = tile_minimizer_kernel<L, HPC>;
-    const int lds = block_lds_bytes<HPC>();
-    // per instantiation AND per device: function attributes and occupancy belong to the device the module is loaded on
-    constexpr int MAX_DEV = 64;
-    static int n_cu_d[MAX_DEV] = {0}, per_cu_d[MAX_DEV] = {0};
-    int dev = 0;
-    S2K_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= MAX_DEV) return hipErrorInvalidDevice;
-    if (n_cu_d[dev] == 0) {
-        S2K_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipDeviceProp_t prop;
-        S2K_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        int occ = 0;
-        S2K_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64 * TW, lds));
-        per_cu_d[dev] = occ < 1 ? 1 : occ;
-        if (const char *e = getenv("S2K_DEBUG_BLOCKS_PER_CU")) per_cu_d[dev] = atoi(e) > 0 ? atoi(e) : per_cu_d[dev]; // occupancy experiments
-        n_cu_d[dev] = prop.multiProcessorCount;
-    }
-    const int n_cu = n_cu_d[dev], per_cu = per_cu_d[dev];
-    uint64_t blocks = (n_tiles + TW - 1) / TW;
-    const uint64_t resident = (uint64_t)n_cu * per_cu;
-    if (blocks > resident) blocks = resident; // persistent: waves loop over the remaining tiles
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * TW), lds, st, bases, read_off, n_reads, n_bases, n_tiles,
-                       tile_read0, sem, rec, pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts);
-    return hipGetLastError();
-}
-
-template <int L>
-hipError_t launch_tiles_l(bool hpc, hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
-                          uint64_t n_bases, uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec,
-                          uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
-                          Counts *counts) {
-    if (hpc)
-        return launch_tiles_lh<L, true>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
-                                        tile_rec_off, tile_cnt, mn_cnt, counts);
-    return launch_tiles_lh<L, false>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
-                                     tile_rec_off, tile_cnt, mn_cnt, counts);
-}
-
-} // namespace
 
 hipError_t launch_tile_index(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles,
                              uint32_t *tile_read0, hipStream_t st) {
@@ -1110,9 +29,12 @@ hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off
     if (n_tiles == 0 || n_reads == 0) return hipSuccess;
     if (sem.l > (uint32_t)MAX_L_TILED || sem.simd_seeds) return hipErrorInvalidValue;
     switch (sem.l) {
-    case 31:
-        return launch_tiles_l<31>(sem.hpc, st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec,
-                                  pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts);
+#define S2K_CASE(LV)                                                                                                   \
+    case LV:                                                                                                           \
+        return launch_tiles_static_##LV(sem.hpc, st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, \
+                                        pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts);
+        S2K_STATIC_LS(S2K_CASE)
+#undef S2K_CASE
     default:
         return launch_tiles_l<0>(sem.hpc, st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec,
                                  pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts);

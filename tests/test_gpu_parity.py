@@ -95,7 +95,7 @@ def test_ragged_batches_all_tile_alignments(eng, oracle):
 def test_l_grid_dynamic_and_static_paths(eng, oracle):
     rng = np.random.default_rng(7)
     reads = [rand_read(rng, int(n), hp=0.25, odd=0.01) for n in rng.integers(0, 30000, size=24)]
-    for l in (1, 2, 4, 5, 7, 10, 11, 17, 25, 28, 31, 32, 33, 47, 64):
+    for l in (1, 2, 4, 5, 7, 10, 11, 12, 15, 17, 21, 25, 28, 31, 32, 33, 47, 64):  # 12, 15, 21, 31 have unrolled instantiations
         for mode in SCALAR:
             compare(eng, oracle, reads, l, 5, 0.02, mode, expect_path=0, tag="lgrid")
     for l in (65, 100, 255):  # beyond the tiled kernel: serial path
