@@ -205,7 +205,7 @@ uint64_t overflow_estimate(uint64_t n_bases, double density) {
 bool tiled_supported(const Sem &s) {
     // the tiled kernel implements the two scalar HashModes (the parity target); the Simd result
     // semantics run on the serial kernels
-    return !s.simd_seeds && s.l <= 64;
+    return !(s.simd_seeds && s.hpc) && s.l <= 64; // HpcSimd's tail rule needs the run count of the whole read
 }
 
 s2k_status enqueue(s2k_ctx *ctx) {

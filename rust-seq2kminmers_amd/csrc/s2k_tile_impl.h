@@ -605,13 +605,28 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                     }
                 }
             }
+            // Lane i holds the END of read r0+c0+i (= start of the next one); its start is the previous lane's value
+            // (rs0 / the previous chunk's last value for lane 0).
+            uint64_t pstart = 0;
+            uint32_t wextra = 0;
+            if constexpr (!HPC) {
+                pstart = ((uint64_t)__shfl_up((uint32_t)(bpos >> 32), 1) << 32) | __shfl_up((uint32_t)bpos, 1);
+                if (lane == 0) pstart = chunk_prev;
+                if (sem.tail_quirk && bpos != ~0ull && bpos - pstart > (uint64_t)l) {
+                    // Simd semantics: the final block of 16 l-mers is lost when their number is a multiple of 16
+                    // (src/nthash_avx512_32.rs:134-138): 16 more positions before this read's end are invalid
+                    const uint64_t sentinel = bpos - pstart - l + 1;
+                    if (sentinel >= 32 && (sentinel & 15) == 0) wextra = 16;
+                }
+            }
             // every lane clears [HB - w, HB - 1] for each boundary of this chunk
             uint64_t todo = __ballot(internal) | (em ? (1ull << first_ext) : 0ull);
             while (todo) {
                 const int z = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const int32_t hbz = (int32_t)bcast((uint32_t)HB, z);
-                const int lo = hbz - (int)wclr - (int)(Tq * lane), hi = hbz - 1 - (int)(Tq * lane); // lane-local, inclusive
+                const int wz = (int)wclr + (HPC ? 0 : (int)bcast(wextra, z));
+                const int lo = hbz - wz - (int)(Tq * lane), hi = hbz - 1 - (int)(Tq * lane); // lane-local, inclusive
                 if (hi >= 0 && lo < (int)Tq) {
 #pragma unroll
                     for (int d = 0; d < 5; d++) {
@@ -626,11 +641,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
             }
             if constexpr (!HPC) {
                 // A read of exactly l bases has one l-mer that fits, but the reference yields nothing unless
-                // seq.len() > l (src/lib.rs:97): clear that position.  Lane i holds the END of read r0+c0+i
-                // (= start of the next one); its start is the previous lane's value (rs0 / the previous chunk's
-                // last value for lane 0).
-                uint64_t pstart = ((uint64_t)__shfl_up((uint32_t)(bpos >> 32), 1) << 32) | __shfl_up((uint32_t)bpos, 1);
-                if (lane == 0) pstart = chunk_prev;
+                // seq.len() > l (src/lib.rs:97): clear that position.
                 const bool exact = bpos != ~0ull && bpos - pstart == (uint64_t)l && pstart >= t0 && pstart < tile_end;
                 uint64_t ex = __ballot(exact);
                 while (ex) {
@@ -880,7 +891,8 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
     for (int c = threadIdx.x; c < 256; c += 64 * TW) {
         // Hpc tiles carry read-start marks in bit 7 (input is 7-bit there), so the table ignores it
         uint32_t cc = HPC ? (c & 0x7F) : c;
-        uint32_t h = seed_h_scalar(cc), r = seed_rc_scalar(cc);
+        // Simd result semantics map bytes by their low nibble (src/nthash_avx512_32.rs:178-193)
+        uint32_t h = sem.simd_seeds ? seed_h_simd(cc) : seed_h_scalar(cc), r = sem.simd_seeds ? seed_rc_simd(cc) : seed_rc_scalar(cc);
         tab[c] = make_uint2(h, rotl32(r, l - 1));
         tab[256 + c] = make_uint2(rotl32(h, l), rotr32(r, 1));
     }

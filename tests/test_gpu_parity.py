@@ -165,7 +165,23 @@ def test_simd_result_semantics(eng, oracle):
     for mode in (HM.Simd, HM.HpcSimd):
         for l in (4, 9, 16, 31):
             for d in (0.02, 0.33, 1.0):
-                compare(eng, oracle, reads, l, 3, d, mode, expect_path=1, tag="simd")
+                # Simd runs on the tiled kernel, HpcSimd (tail rule needs the whole read's run count) on the serial one
+                compare(eng, oracle, reads, l, 3, d, mode, expect_path=0 if mode == HM.Simd else 1, tag="simd")
+
+
+def test_simd_tail_rule_across_tiles(eng, oracle):
+    """Simd semantics on the tiled kernel: reads whose l-mer count is a multiple of 16 lose their last 16 l-mers
+    (src/nthash_avx512_32.rs:134-138); make such reads end before, on and after tile boundaries (9216 bases)."""
+    rng = np.random.default_rng(21)
+    for l in (12, 31, 17):
+        lens = [l - 1 + 16 * int(m) for m in rng.integers(1, 700, size=120)]          # every read triggers the rule (or is < 32 l-mers)
+        lens += [int(x) for x in rng.integers(0, 12000, size=60)]                      # ordinary neighbours
+        lens += [9216 - (l - 1 + 16 * 40) % 9216, l - 1 + 16 * 40, 9216, l - 1 + 16 * 576]  # ends aligned with tile edges
+        order = rng.permutation(len(lens))
+        reads = [rand_read(rng, lens[i], odd=0.02) for i in order]
+        for d in (0.01, 0.5):
+            compare(eng, oracle, reads, l, 4, d, HM.Simd, expect_path=0, tag="simd-tail")
+            compare(eng, oracle, reads, l, 4, d, HM.Simd, force_serial=True, expect_path=1, tag="simd-tail-serial")
 
 
 def test_status_codes(eng):
