@@ -203,9 +203,8 @@ uint64_t overflow_estimate(uint64_t n_bases, double density) {
 }
 
 bool tiled_supported(const Sem &s) {
-    // the tiled kernel implements the two scalar HashModes (the parity target); the Simd result
-    // semantics run on the serial kernels
-    return !(s.simd_seeds && s.hpc) && s.l <= 64; // HpcSimd's tail rule needs the run count of the whole read
+    // all four HashModes; HpcSimd first counts the runs of every read (its tail rule depends on that number)
+    return s.l <= 64;
 }
 
 s2k_status enqueue(s2k_ctx *ctx) {
@@ -219,6 +218,10 @@ s2k_status enqueue(s2k_ctx *ctx) {
     Arena a{nullptr, 0, 0};
     uint32_t *mn_cnt = nullptr, *tile_read0 = nullptr, *tile_cnt = nullptr;
     uint64_t *mn_off = nullptr, *tile_rec_off = nullptr, *tile_goff = nullptr, *scan_tmp = nullptr, *pool_cursor = nullptr;
+    const bool want_runs = !c.serial && c.sem.hpc && c.sem.tail_quirk; // HpcSimd on the tiled kernel
+    const uint64_t n_runblk = n_bases / 256 + 1;
+    uint32_t *run_blk = nullptr, *read_runs = nullptr;
+    uint64_t *run_off = nullptr, *run_tmp = nullptr;
     Records rec{};
     for (int pass = 0; pass < 2; pass++) {
         a.off = 0;
@@ -232,6 +235,12 @@ s2k_status enqueue(s2k_ctx *ctx) {
             tile_cnt = a.take<uint32_t>(n_tiles + 1);
             tile_rec_off = a.take<uint64_t>(n_tiles + 1);
             tile_goff = a.take<uint64_t>(n_tiles + 1);
+        }
+        if (want_runs) {
+            run_blk = a.take<uint32_t>(n_runblk + 1);
+            run_off = a.take<uint64_t>(n_runblk + 2);
+            run_tmp = a.take<uint64_t>(scan_tmp_bytes(n_runblk) / sizeof(uint64_t) + 1);
+            read_runs = a.take<uint32_t>(n_reads + 1);
         }
         const uint64_t rec_total = c.serial ? c.pool_cap : n_tiles * c.slab_cap + c.pool_cap;
         rec.j = a.take<uint32_t>(rec_total);
@@ -279,8 +288,15 @@ s2k_status enqueue(s2k_ctx *ctx) {
     } else {
         S2K_TRY(hipMemsetAsync(mn_cnt, 0, (n_reads + 1) * sizeof(uint32_t), st), "memset mn_cnt");
         S2K_TRY(launch_tile_index(c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, st), "tile index kernel");
+        Sem sem = c.sem;
+        sem.read_runs = nullptr;
+        if (want_runs) {
+            S2K_TRY(launch_read_run_counts(c.d_bases, c.d_read_off, n_reads, n_bases, run_blk, run_off, run_tmp, read_runs, st),
+                    "run count kernels");
+            sem.read_runs = read_runs;
+        }
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
-        S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, c.sem, rec, pool_cursor,
+        S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
                                        tile_rec_off, tile_cnt, mn_cnt, ctx->d_counts, st),
                 "tiled minimizer kernel");
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");

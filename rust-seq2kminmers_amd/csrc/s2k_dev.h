@@ -52,6 +52,8 @@ struct Sem {
     uint32_t end_kind;   // 0: j+l-1 (lib.rs:202,226)  1: st[p+l]-1 (nthash_hpc.rs:281)  2: st[p+l-1] (nthash_hpc_simd.rs:64)
     uint32_t tail_quirk; // drop the final 16-block when #l-mers % 16 == 0 (src/nthash_avx512_32.rs:134-138)
     uint32_t dbg_skip;   // timing ablations only (env S2K_DEBUG_SKIP; results are wrong when set): 1 hash loop, 2 dense phase, 4 hpc compaction
+    uint32_t pad_;
+    const uint32_t *read_runs; // HpcSimd on the tiled kernel: number of runs of every read (launch_read_run_counts), else null
 };
 
 struct Counts { // mirrored by s2k_counts (include/s2k.h)
@@ -99,6 +101,11 @@ struct Records { // SoA pool of minimizer records written by the minimizer kerne
 hipError_t launch_scan_u32(const uint32_t *in, uint64_t n, uint64_t *out /*n+1*/, uint64_t *block_tmp,
                            uint32_t sub_k /*0: identity, else max(0,x-sub_k+1)*/, hipStream_t st);
 size_t scan_tmp_bytes(uint64_t n);
+
+// runs[r] = number of homopolymer runs of read r (equal adjacent bytes collapse; a read start always begins a run).
+// blk_cnt: n_bases/256+1 u32, blk_off: n_bases/256+2 u64, scan_tmp: scan_tmp_bytes(n_bases/256+1).
+hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
+                                  uint32_t *blk_cnt, uint64_t *blk_off, uint64_t *scan_tmp, uint32_t *runs, hipStream_t st);
 
 hipError_t launch_synth(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d, hipStream_t st);
 

@@ -27,7 +27,7 @@ hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off
                                   uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
                                   Counts *counts, hipStream_t st) {
     if (n_tiles == 0 || n_reads == 0) return hipSuccess;
-    if (sem.l > (uint32_t)MAX_L_TILED || (sem.simd_seeds && sem.hpc)) return hipErrorInvalidValue; // HpcSimd: serial kernels
+    if (sem.l > (uint32_t)MAX_L_TILED || (sem.hpc && sem.tail_quirk && !sem.read_runs)) return hipErrorInvalidValue;
     switch (sem.l) {
 #define S2K_CASE(LV)                                                                                                   \
     case LV:                                                                                                           \

@@ -434,13 +434,15 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         else pass2(std::false_type{});
     }
     S2K_STAMP(15); // compaction: byte stores
-    // 5. run heads that follow the tile: up to l of them (hash needs l-1, the end position one more)
+    // 5. run heads that follow the tile: up to l of them (hash needs l-1, the end position one more); the HpcSimd
+    //    tail rule looks 16 heads further for the end of the read
+    const uint32_t hl = sem.tail_quirk ? l + 16 : l;
     uint32_t halo_n = 0;
     if (!partial) {
         uint64_t q = t0 + TILE_BASES;
         uint32_t pb = last_raw;
         bool first = true;
-        while (halo_n < l && q < n_bases) { // wave-uniform
+        while (halo_n < hl && q < n_bases) { // wave-uniform
             const uint32_t span = first ? 128u : 256u; // bytes examined this round
             uint64_t a = q + 4 * (uint64_t)lane;
             int nval = (a >= n_bases || 4u * (uint32_t)lane >= span) ? 0 : (n_bases - a >= 4 ? 4 : (int)(n_bases - a));
@@ -465,7 +467,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 if (t & (0x80u << (8 * b))) {
-                    if (idx < l) {
+                    if (idx < hl) {
                         D[R + idx] = (uint8_t)(wv >> (8 * b));
                         S.halo_pos[idx] = (uint32_t)(a - t0) + b;
                     }
@@ -477,7 +479,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
             q += span;
             first = false;
         }
-        if (halo_n > l) halo_n = l;
+        if (halo_n > hl) halo_n = hl;
     }
     halo_n_out = halo_n;
     wave_sync();
@@ -551,7 +553,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
     //     before the next read, src/lib.rs:215-230; w = l run heads for Hpc: head x+l must exist in the
     //     same read, src/nthash_hpc.rs:265-267).  The first read start at or after the tile end (or the
     //     end of the stream) is the one external boundary.
-    const uint32_t wclr = HPC ? l : l - 1;
+    const uint32_t wclr = HPC ? (sem.keep_last ? l - 1 : l) : l - 1; // Hpc drops the last l-mer of a read (src/nthash_hpc.rs:265-267)
     const uint32_t rcpTq = 0xFFFFFFFFu / Tq + 1u; // x / Tq == umulhi(x, rcpTq) for x < 2^16 (Tq <= 144)
     uint32_t vm[5]; // validated hit mask of this lane
     {
@@ -609,6 +611,21 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
             // (rs0 / the previous chunk's last value for lane 0).
             uint64_t pstart = 0;
             uint32_t wextra = 0;
+            if constexpr (HPC) {
+                if (sem.tail_quirk) { // HpcSimd (src/nthash_hpc_simd.rs:35-68): same rule on the run count of the whole read
+                    pstart = ((uint64_t)__shfl_up((uint32_t)(bpos >> 32), 1) << 32) | __shfl_up((uint32_t)bpos, 1);
+                    if (lane == 0) pstart = chunk_prev;
+                    if ((internal || (external && lane == first_ext)) && bpos != ~0ull) {
+                        const uint32_t Rr = sem.read_runs[(uint64_t)r0 + c0 + lane]; // lane holds the end of that read
+                        if (bpos - pstart <= (uint64_t)l) wextra = 1;              // seq.len() <= l yields nothing (src/lib.rs:97)
+                        else if (Rr >= l) {
+                            const uint32_t sentinel = Rr - l + 1;
+                            if (sentinel >= 32 && (sentinel & 15) == 0) wextra = 16;
+                        }
+                    }
+                    chunk_prev = ((uint64_t)bcast((uint32_t)(bpos >> 32), 63) << 32) | bcast((uint32_t)bpos, 63);
+                }
+            }
             if constexpr (!HPC) {
                 pstart = ((uint64_t)__shfl_up((uint32_t)(bpos >> 32), 1) << 32) | __shfl_up((uint32_t)bpos, 1);
                 if (lane == 0) pstart = chunk_prev;
@@ -625,7 +642,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 const int z = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const int32_t hbz = (int32_t)bcast((uint32_t)HB, z);
-                const int wz = (int)wclr + (HPC ? 0 : (int)bcast(wextra, z));
+                const int wz = (int)wclr + (int)bcast(wextra, z);
                 const int lo = hbz - wz - (int)(Tq * lane), hi = hbz - 1 - (int)(Tq * lane); // lane-local, inclusive
                 if (hi >= 0 && lo < (int)Tq) {
 #pragma unroll
@@ -809,9 +826,14 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 if (act[u]) {
                     if constexpr (HPC) {
                         uint32_t rp = 0, re = 0;
-                        hpc_rawpos2(S, x[u], l, nh, halo_n, Tq, rcpTq, rp, re); // head x + l exists: the hit survived validation
+                        if (sem.end_kind == 2) { // HpcSimd: start of the last run, st[p+l-1] (src/nthash_hpc_simd.rs:64)
+                            hpc_rawpos2(S, x[u], l - 1, nh, halo_n, Tq, rcpTq, rp, re);
+                            e1[u] = t0 + re;
+                        } else {
+                            hpc_rawpos2(S, x[u], l, nh, halo_n, Tq, rcpTq, rp, re); // head x + l exists: the hit survived validation
+                            e1[u] = t0 + re - 1; // st[p+l] - 1, src/nthash_hpc.rs:281
+                        }
                         p[u] = t0 + rp;
-                        e1[u] = t0 + re - 1; // st[p+l] - 1, src/nthash_hpc.rs:281
                     } else {
                         p[u] = t0 + x[u];
                         e1[u] = p[u] + l - 1; // src/lib.rs:226

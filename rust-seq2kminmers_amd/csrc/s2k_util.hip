@@ -188,4 +188,87 @@ hipError_t launch_finalize(Counts *counts, const uint64_t *xor_shards, const uin
     return hipGetLastError();
 }
 
+
+// ---- runs per read (HpcSimd tail rule needs the run count of the whole read) ---------------------------------
+// neq(q) = q == 0 || s[q] != s[q-1].  Pass 1 counts neq over 256-byte blocks of the stream, a scan turns the counts
+// into prefixes, pass 2 evaluates the prefix C at both ends of every read (at most 255 bytes each) and
+// runs = C(end) - C(start) + (neq(start) ? 0 : 1): a read start begins a run even inside a homopolymer.
+namespace {
+constexpr int RUN_BLK = 256;
+
+__global__ __launch_bounds__(256) void run_block_counts(const uint8_t *__restrict__ s, uint64_t n, uint32_t *__restrict__ cnt) {
+    const uint64_t q0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; // 16 bytes per thread, 16 threads per block of 256
+    uint32_t c = 0;
+    if (q0 < n) {
+        uint32_t prev = q0 ? s[q0 - 1] : 0x100u;
+        if (q0 + 16 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(s + q0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t prv = (w[i] << 8) | (prev & 0xFFu);
+                uint32_t x = w[i] ^ prv; // byte j != 0 <=> s[q] != s[q-1]
+                uint32_t nz = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu | x) & 0x80808080u;
+                if (i == 0 && prev == 0x100u) nz |= 0x80u; // q == 0
+                c += __popc(nz);
+                prev = w[i] >> 24;
+            }
+        } else {
+            for (uint64_t q = q0; q < n; q++) {
+                const uint32_t b = s[q];
+                c += (prev == 0x100u || b != prev) ? 1u : 0u;
+                prev = b;
+            }
+        }
+    }
+    // 16 consecutive threads share a block
+    c += __shfl_xor(c, 1);
+    c += __shfl_xor(c, 2);
+    c += __shfl_xor(c, 4);
+    c += __shfl_xor(c, 8);
+    const uint64_t blk = q0 / RUN_BLK;
+    if ((threadIdx.x & 15) == 0 && blk * RUN_BLK < n + RUN_BLK) cnt[blk] = c;
+}
+
+__device__ inline uint64_t run_prefix(const uint8_t *__restrict__ s, const uint64_t *__restrict__ blk_off, uint64_t b) {
+    const uint64_t blk = b / RUN_BLK;
+    uint64_t c = blk_off[blk];
+    uint64_t q = blk * RUN_BLK;
+    uint32_t prev = q ? s[q - 1] : 0x100u;
+    for (; q < b; q++) {
+        const uint32_t v = s[q];
+        c += (prev == 0x100u || v != prev) ? 1u : 0u;
+        prev = v;
+    }
+    return c;
+}
+
+__global__ void read_run_counts(const uint8_t *__restrict__ s, const uint64_t *__restrict__ read_off, uint64_t n_reads,
+                                const uint64_t *__restrict__ blk_off, uint32_t *__restrict__ runs) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t a = read_off[r], b = read_off[r + 1];
+    uint32_t R = 0;
+    if (b > a) {
+        const uint64_t ca = run_prefix(s, blk_off, a), cb = run_prefix(s, blk_off, b);
+        const bool neq_a = a == 0 || s[a] != s[a - 1];
+        R = (uint32_t)(cb - ca) + (neq_a ? 0u : 1u);
+    }
+    runs[r] = R;
+}
+} // namespace
+
+hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
+                                  uint32_t *blk_cnt, uint64_t *blk_off, uint64_t *scan_tmp, uint32_t *runs, hipStream_t st) {
+    if (n_reads == 0) return hipSuccess;
+    const uint64_t nblk = n_bases / RUN_BLK + 1; // the block that holds position n_bases exists too (count 0 past the end)
+    const uint64_t threads = nblk * 16;
+    hipLaunchKernelGGL(run_block_counts, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, bases, n_bases, blk_cnt);
+    hipError_t e = launch_scan_u32(blk_cnt, nblk, blk_off, scan_tmp, 0, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(read_run_counts, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, bases, read_off, n_reads,
+                       blk_off, runs);
+    return hipGetLastError();
+}
+
 } // namespace s2k

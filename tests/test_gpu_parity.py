@@ -165,8 +165,8 @@ def test_simd_result_semantics(eng, oracle):
     for mode in (HM.Simd, HM.HpcSimd):
         for l in (4, 9, 16, 31):
             for d in (0.02, 0.33, 1.0):
-                # Simd runs on the tiled kernel, HpcSimd (tail rule needs the whole read's run count) on the serial one
-                compare(eng, oracle, reads, l, 3, d, mode, expect_path=0 if mode == HM.Simd else 1, tag="simd")
+                compare(eng, oracle, reads, l, 3, d, mode, expect_path=0, tag="simd")  # both on the tiled kernel
+                compare(eng, oracle, reads, l, 3, d, mode, force_serial=True, expect_path=1, tag="simd-serial")
 
 
 def test_simd_tail_rule_across_tiles(eng, oracle):
@@ -182,6 +182,34 @@ def test_simd_tail_rule_across_tiles(eng, oracle):
         for d in (0.01, 0.5):
             compare(eng, oracle, reads, l, 4, d, HM.Simd, expect_path=0, tag="simd-tail")
             compare(eng, oracle, reads, l, 4, d, HM.Simd, force_serial=True, expect_path=1, tag="simd-tail-serial")
+
+
+def test_hpcsimd_tail_rule_across_tiles(eng, oracle):
+    """HpcSimd on the tiled kernel: the tail rule applies to the number of RUNS of the whole read (counted by a
+    pre-pass), the end position is the start of the last run, the last HPC l-mer is kept.  Reads are built from runs so
+    that the run count is controlled: R = l - 1 + 16 m triggers the rule; lengths up to several tiles."""
+    rng = np.random.default_rng(22)
+
+    def from_runs(nruns, stretch=0.0):
+        if nruns == 0:
+            return b""
+        letters = rng.integers(0, 4, size=nruns)
+        letters[1:] = (letters[:-1] + 1 + rng.integers(0, 3, size=nruns - 1)) % 4  # adjacent runs differ
+        reps = rng.choice([1, 2, 3, 5, 9], size=nruns, p=[0.6, 0.2, 0.1, 0.07, 0.03])
+        if stretch:
+            m = rng.random(nruns) < stretch
+            reps[m] = rng.integers(40, 400, size=int(m.sum()))
+        return np.repeat(np.frombuffer(b"ACGT", dtype=np.uint8)[letters], reps).tobytes()
+
+    for l in (12, 31, 7):
+        nruns = [l - 1 + 16 * int(m) for m in rng.integers(1, 900, size=90)] + [int(x) for x in rng.integers(0, 9000, size=50)]
+        nruns += [l - 1, l, l + 1, l + 15, l + 16, l + 30, l + 31, l + 32, l - 1 + 32, l - 1 + 48]
+        order = rng.permutation(len(nruns))
+        reads = [from_runs(nruns[i], stretch=0.002 if i % 5 == 0 else 0.0) for i in order]
+        reads += [b"A" * 500, b"ACGT" * 8, bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.arange(l) % 4])]  # one run; no runs; exactly l bases
+        for d in (0.01, 0.5):
+            compare(eng, oracle, reads, l, 4, d, HM.HpcSimd, expect_path=0, tag="hpcsimd-tail")
+            compare(eng, oracle, reads, l, 4, d, HM.HpcSimd, force_serial=True, expect_path=1, tag="hpcsimd-tail-serial")
 
 
 def test_status_codes(eng):
