@@ -291,7 +291,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
         Sem sem = c.sem;
         sem.read_runs = nullptr;
         if (want_runs) {
-            S2K_TRY(launch_read_run_counts(c.d_bases, c.d_read_off, n_reads, n_bases, run_blk, run_off, run_tmp, read_runs, st),
+            S2K_TRY(launch_read_run_counts(c.d_bases, c.d_read_off, n_reads, n_bases, run_blk, run_off, run_tmp, read_runs, nullptr, st),
                     "run count kernels");
             sem.read_runs = read_runs;
         }
@@ -672,21 +672,40 @@ s2k_status s2k_hpc_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *
     if (!ctx || !d_read_off || !d_hpc_off || (!d_bases && n_bases)) return S2K_ERR_INVALID_ARG;
     S2K_TRY(hipSetDevice(ctx->device), "set device");
     if (ctx->pending) (void)finish(ctx, nullptr);
+    // segment-parallel path (16-byte aligned bases, stream starting at offset 0); else one thread per read
+    const bool seg_path = n_reads && n_bases && ((uintptr_t)d_bases & 15) == 0;
+    const uint64_t nblk = n_bases / 256 + 1;
     Arena a{nullptr, 0, 0};
-    uint32_t *cnt = nullptr;
-    uint64_t *tmp = nullptr;
+    uint32_t *cnt = nullptr, *blk_cnt = nullptr;
+    uint64_t *tmp = nullptr, *blk_off = nullptr, *blk_tmp = nullptr, *read_c0 = nullptr;
     for (int pass = 0; pass < 2; pass++) {
         a.off = 0;
         cnt = a.take<uint32_t>(n_reads + 1);
         tmp = a.take<uint64_t>(scan_tmp_bytes(n_reads) / sizeof(uint64_t) + 1);
+        if (seg_path) {
+            blk_cnt = a.take<uint32_t>(nblk + 1);
+            blk_off = a.take<uint64_t>(nblk + 2);
+            blk_tmp = a.take<uint64_t>(scan_tmp_bytes(nblk) / sizeof(uint64_t) + 1);
+            read_c0 = a.take<uint64_t>(n_reads + 1);
+        }
         if (pass == 0) {
             S2K_TRY(ctx->ws.ensure(a.off + 256), "workspace allocation");
             a.base = (char *)ctx->ws.p;
         }
     }
-    S2K_TRY(launch_hpc_count(d_bases, d_read_off, n_reads, cnt, ctx->stream), "hpc count kernel");
-    S2K_TRY(launch_scan_u32(cnt, n_reads, d_hpc_off, tmp, 0, ctx->stream), "scan");
-    if (d_hpc || d_pos) S2K_TRY(launch_hpc_write(d_bases, d_read_off, n_reads, d_hpc_off, d_hpc, d_pos, capacity, ctx->stream), "hpc write kernel");
+    if (seg_path) {
+        S2K_TRY(launch_read_run_counts(d_bases, d_read_off, n_reads, n_bases, blk_cnt, blk_off, blk_tmp, cnt, read_c0, ctx->stream),
+                "run count kernels");
+        S2K_TRY(launch_scan_u32(cnt, n_reads, d_hpc_off, tmp, 0, ctx->stream), "scan");
+        if (d_hpc || d_pos)
+            S2K_TRY(launch_hpc_segments(d_bases, d_read_off, n_reads, n_bases, d_hpc_off, blk_off, read_c0, d_hpc, d_pos, capacity,
+                                        ctx->stream),
+                    "hpc segment kernel");
+    } else {
+        S2K_TRY(launch_hpc_count(d_bases, d_read_off, n_reads, cnt, ctx->stream), "hpc count kernel");
+        S2K_TRY(launch_scan_u32(cnt, n_reads, d_hpc_off, tmp, 0, ctx->stream), "scan");
+        if (d_hpc || d_pos) S2K_TRY(launch_hpc_write(d_bases, d_read_off, n_reads, d_hpc_off, d_hpc, d_pos, capacity, ctx->stream), "hpc write kernel");
+    }
     uint64_t total = 0;
     S2K_TRY(hipMemcpyAsync(&total, d_hpc_off + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H");
     S2K_TRY(hipStreamSynchronize(ctx->stream), "sync");

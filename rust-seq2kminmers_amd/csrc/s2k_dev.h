@@ -103,9 +103,16 @@ hipError_t launch_scan_u32(const uint32_t *in, uint64_t n, uint64_t *out /*n+1*/
 size_t scan_tmp_bytes(uint64_t n);
 
 // runs[r] = number of homopolymer runs of read r (equal adjacent bytes collapse; a read start always begins a run).
-// blk_cnt: n_bases/256+1 u32, blk_off: n_bases/256+2 u64, scan_tmp: scan_tmp_bytes(n_bases/256+1).
+// blk_cnt: n_bases/256+1 u32, blk_off: n_bases/256+2 u64 (prefix of neq-counts per 256-byte block), scan_tmp:
+// scan_tmp_bytes(n_bases/256+1).  read_c0 (optional, n_reads u64): that prefix evaluated at the start of every read.
 hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
-                                  uint32_t *blk_cnt, uint64_t *blk_off, uint64_t *scan_tmp, uint32_t *runs, hipStream_t st);
+                                  uint32_t *blk_cnt, uint64_t *blk_off, uint64_t *scan_tmp, uint32_t *runs, uint64_t *read_c0,
+                                  hipStream_t st);
+// Standalone homopolymer compression, segment-parallel (s2k_hpc_seg.hip): the compressed bytes and read-relative run
+// starts of the whole batch, given hpc_off (= prefix of runs[]), blk_off and read_c0 from launch_read_run_counts.
+hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
+                               const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint8_t *o_hpc,
+                               uint32_t *o_pos, uint64_t capacity, hipStream_t st);
 
 hipError_t launch_synth(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d, hipStream_t st);
 

@@ -1,0 +1,133 @@
+// s2k_hpc_seg.hip -- standalone homopolymer compression at stream speed.
+// What it replaces: hpc() / encode_rle_simd() of the reference (src/hpc.rs:28-41, :44-147): per read the compressed
+// string and the start of every run.  The reference walks a read sequentially (16 bytes per AVX-512 step); here the
+// batch is cut into 4096-byte segments regardless of read boundaries.  A segment's first output slot follows from two
+// prefixes made by launch_read_run_counts -- runs before the segment start inside its read -- plus hpc_off of that
+// read; inside the segment a block scan places every run head, and a running max carries the start of the current
+// read so that positions come out read-relative.  Outputs of the whole batch are contiguous in read order, so the
+// stores are coalesced.
+#include "s2k_dev.h"
+
+namespace s2k {
+namespace {
+
+constexpr int HS_THREADS = 256;
+constexpr uint32_t HS_SEG = HS_THREADS * 16;
+
+__global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
+    const uint8_t *__restrict__ s, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
+    const uint64_t *__restrict__ hpc_off, const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ read_c0,
+    uint8_t *__restrict__ o_hpc, uint32_t *__restrict__ o_pos, uint64_t capacity) {
+    __shared__ uint32_t starts[HS_SEG / 32]; // bit i: a non-empty read starts at seg + i
+    __shared__ uint32_t ls[HS_THREADS], lm[HS_THREADS];
+    __shared__ uint64_t sh_r, sh_g, sh_start;
+    const int t = threadIdx.x;
+    const uint64_t seg = (uint64_t)blockIdx.x * HS_SEG, seg_end = seg + HS_SEG;
+    if (t < (int)(HS_SEG / 32)) starts[t] = 0;
+    if (t == 0) {
+        // read that contains the first byte of the segment: last r with read_off[r] <= seg (non-empty by construction)
+        uint64_t lo = 0, hi = n_reads - 1;
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo + 1) / 2;
+            if (read_off[mid] <= seg) lo = mid;
+            else hi = mid - 1;
+        }
+        const uint64_t a = read_off[lo];
+        uint64_t g = hpc_off[lo];
+        if (seg > a) { // runs of that read before the segment
+            const bool neq_a = a == 0 || s[a] != s[a - 1];
+            g += blk_off[seg / 256] - read_c0[lo] + (neq_a ? 0u : 1u);
+        }
+        sh_r = lo;
+        sh_g = g;
+        sh_start = a;
+    }
+    __syncthreads();
+    const uint64_t r_s = sh_r;
+    // starts of the non-empty reads inside the segment (read r_s itself when it starts exactly here)
+    for (uint64_t i = (read_off[r_s] == seg ? 0 : 1) + (uint64_t)t;; i += HS_THREADS) {
+        const uint64_t r = r_s + i;
+        bool more = false;
+        if (r < n_reads) {
+            const uint64_t a = read_off[r];
+            if (a < seg_end) {
+                more = true;
+                if (a >= seg && read_off[r + 1] > a) atomicOr(&starts[(a - seg) >> 5], 1u << ((a - seg) & 31));
+            }
+        }
+        if (!__syncthreads_or(more)) break;
+    }
+    __syncthreads();
+    // this thread's 16 bytes
+    const uint64_t q0 = seg + 16 * (uint64_t)t;
+    uint32_t c[16];
+    uint32_t prev = 0x100u;
+    int nval = 0;
+    if (q0 < n_bases) {
+        nval = n_bases - q0 >= 16 ? 16 : (int)(n_bases - q0);
+        if (q0) prev = s[q0 - 1];
+        if (nval == 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(s + q0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 16; j++) c[j] = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) c[j] = j < nval ? s[q0 + j] : 0u;
+        }
+    }
+    const uint32_t sb = (starts[(16 * t) >> 5] >> ((16 * t) & 31)) & 0xFFFFu;
+    uint32_t heads = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (j < nval && (c[j] != prev || ((sb >> j) & 1))) heads |= 1u << j;
+        prev = j < nval ? c[j] : prev;
+    }
+    const uint32_t last_start = sb ? (uint32_t)(16 * t + (31 - __clz(sb)) + 1) : 0u; // segment-relative + 1
+    // block-wide exclusive sum of head counts and exclusive max of start positions
+    ls[t] = __popc(heads);
+    lm[t] = last_start;
+    __syncthreads();
+#pragma unroll
+    for (int d = 1; d < HS_THREADS; d <<= 1) {
+        uint32_t a = 0, b = 0;
+        if (t >= d) {
+            a = ls[t - d];
+            b = lm[t - d];
+        }
+        __syncthreads();
+        if (t >= d) {
+            ls[t] += a;
+            lm[t] = lm[t] > b ? lm[t] : b;
+        }
+        __syncthreads();
+    }
+    uint64_t slot = sh_g + (t ? ls[t - 1] : 0u);
+    const uint32_t carry = t ? lm[t - 1] : 0u;
+    uint64_t cur = carry ? seg + carry - 1 : sh_start; // start of the read the current byte belongs to
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if ((sb >> j) & 1) cur = q0 + j;
+        if ((heads >> j) & 1) {
+            if (slot < capacity) {
+                if (o_hpc) o_hpc[slot] = (uint8_t)c[j];
+                if (o_pos) o_pos[slot] = (uint32_t)(q0 + j - cur);
+            }
+            slot++;
+        }
+    }
+}
+
+} // namespace
+
+hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
+                               const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint8_t *o_hpc,
+                               uint32_t *o_pos, uint64_t capacity, hipStream_t st) {
+    if (n_reads == 0 || n_bases == 0) return hipSuccess;
+    const uint64_t segs = (n_bases + HS_SEG - 1) / HS_SEG;
+    hipLaunchKernelGGL(hpc_segment_kernel, dim3((unsigned)segs), dim3(HS_THREADS), 0, st, bases, read_off, n_reads, n_bases,
+                       hpc_off, blk_off, read_c0, o_hpc, o_pos, capacity);
+    return hipGetLastError();
+}
+
+} // namespace s2k

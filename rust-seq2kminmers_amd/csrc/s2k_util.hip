@@ -244,11 +244,12 @@ __device__ inline uint64_t run_prefix(const uint8_t *__restrict__ s, const uint6
 }
 
 __global__ void read_run_counts(const uint8_t *__restrict__ s, const uint64_t *__restrict__ read_off, uint64_t n_reads,
-                                const uint64_t *__restrict__ blk_off, uint32_t *__restrict__ runs) {
+                                const uint64_t *__restrict__ blk_off, uint32_t *__restrict__ runs, uint64_t *__restrict__ read_c0) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const uint64_t a = read_off[r], b = read_off[r + 1];
     uint32_t R = 0;
+    if (read_c0) read_c0[r] = b > a ? run_prefix(s, blk_off, a) : 0;
     if (b > a) {
         const uint64_t ca = run_prefix(s, blk_off, a), cb = run_prefix(s, blk_off, b);
         const bool neq_a = a == 0 || s[a] != s[a - 1];
@@ -259,7 +260,8 @@ __global__ void read_run_counts(const uint8_t *__restrict__ s, const uint64_t *_
 } // namespace
 
 hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
-                                  uint32_t *blk_cnt, uint64_t *blk_off, uint64_t *scan_tmp, uint32_t *runs, hipStream_t st) {
+                                  uint32_t *blk_cnt, uint64_t *blk_off, uint64_t *scan_tmp, uint32_t *runs, uint64_t *read_c0,
+                                  hipStream_t st) {
     if (n_reads == 0) return hipSuccess;
     const uint64_t nblk = n_bases / RUN_BLK + 1; // the block that holds position n_bases exists too (count 0 past the end)
     const uint64_t threads = nblk * 16;
@@ -267,7 +269,7 @@ hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off
     hipError_t e = launch_scan_u32(blk_cnt, nblk, blk_off, scan_tmp, 0, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(read_run_counts, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, bases, read_off, n_reads,
-                       blk_off, runs);
+                       blk_off, runs, read_c0);
     return hipGetLastError();
 }
 

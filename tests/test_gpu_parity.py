@@ -292,6 +292,51 @@ def test_standalone_hpc(eng, oracle, ecoli):
     assert pkg.hpc(b"AACCCGTTTTT", engine=eng) == b"ACGT"
 
 
+def test_standalone_hpc_batches(eng, oracle):
+    """s2k_hpc_device on ragged batches (segment-parallel path): reads that start inside a homopolymer, empty and
+    one-base reads, runs longer than a 4096-byte segment, boundaries on segment edges; also the one-thread-per-read
+    path taken for an unaligned base pointer."""
+    import torch
+
+    rng = np.random.default_rng(41)
+    dev = torch.device("cuda", 0)
+    lens = [0, 1, 2, 4096, 4095, 4097, 1, 0, 8192, 30000, 12288 - 5, 5, 0, 70000] + [int(x) for x in rng.integers(0, 9000, size=150)]
+    reads = [rand_read(rng, n, hp=0.4) for n in lens]
+    reads[9] = b"A" * 30000                      # one run spanning several segments
+    reads[13] = reads[13][:100] + b"C" * 9000 + reads[13][9100:]
+    reads[20] = b"T" * len(reads[20])            # neighbours of equal letters: read starts are forced run heads
+    reads[21] = b"T" * max(len(reads[21]), 3)
+    reads[22] = b"T" + reads[22]
+    bases, off = pkg.pack_reads(reads)
+    exp_s, exp_p, exp_off = [], [], [0]
+    for r in reads:
+        cs, cp = oracle.hpc(r, 2) if len(r) else (b"", np.zeros(0, dtype=np.uint64))
+        exp_s.append(cs)
+        exp_p.append(np.asarray(cp, dtype=np.uint32))
+        exp_off.append(exp_off[-1] + len(cs))
+    exp_s, exp_p = b"".join(exp_s), np.concatenate(exp_p)
+    for shift in (0, 1):  # 1: unaligned base pointer -> read-serial kernels
+        d_b = torch.zeros(len(bases) + 32, dtype=torch.uint8, device=dev)
+        d_b[shift:shift + len(bases)] = torch.from_numpy(bases).to(dev)
+        d_o = torch.from_numpy(off.astype(np.int64)).to(dev)
+        d_ho = torch.zeros(len(reads) + 1, dtype=torch.int64, device=dev)
+        d_h = torch.zeros(len(bases) + 1, dtype=torch.uint8, device=dev)
+        d_p = torch.zeros(len(bases) + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        n = eng.hpc_device(d_b.data_ptr() + shift, d_o.data_ptr(), len(reads), len(bases), d_ho.data_ptr(), d_h.data_ptr(), d_p.data_ptr(), len(bases))
+        assert n == len(exp_s)
+        assert list(d_ho.cpu().numpy()) == exp_off
+        assert d_h[:n].cpu().numpy().tobytes() == exp_s
+        assert (d_p[:n].cpu().numpy().view(np.uint32) == exp_p).all()
+        # sizes only (no output arrays), then a capacity that is too small
+        assert eng.hpc_device(d_b.data_ptr() + shift, d_o.data_ptr(), len(reads), len(bases), d_ho.data_ptr(), 0, 0, 0) == n
+        d_h.zero_()
+        with pytest.raises(pkg.S2kError) as e:
+            eng.hpc_device(d_b.data_ptr() + shift, d_o.data_ptr(), len(reads), len(bases), d_ho.data_ptr(), d_h.data_ptr(), d_p.data_ptr(), n // 2)
+        assert e.value.status == 7
+        assert d_h[:n // 2].cpu().numpy().tobytes() == exp_s[:n // 2] and int(d_h[n // 2:].max().item()) == 0
+
+
 def test_synthetic_config2_sample_properties(eng, oracle):
     """BASELINE config 2 shape (10 kbp uniform reads, l=31 k=10 d=0.01) at a size the oracle finishes in
     seconds: full comparison, and tiled == serial."""

@@ -24,3 +24,13 @@ for mode in pkg.HashMode:
         c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_reads * L, 31, 10, 0.01, int(mode), o, flags=flags)
         dt = time.perf_counter() - t0
         print("%-8s %-12s path=%d  %.1f Gbp/s  kminmers=%d" % (mode.name, "force_serial" if flags else "default", c["path"], n_reads * L / dt / 1e9, c["n_kminmers"]), flush=True)
+# standalone homopolymer compression (s2k_hpc_device): compressed bytes + run starts of the whole batch
+d_ho = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)
+d_h = torch.empty(n_reads * L, dtype=torch.uint8, device=dev)
+d_p = torch.empty(n_reads * L, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+for rep in range(2):
+    t0 = time.perf_counter()
+    n = eng.hpc_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_reads * L, d_ho.data_ptr(), d_h.data_ptr(), d_p.data_ptr(), n_reads * L)
+    dt = time.perf_counter() - t0
+print("s2k_hpc_device (string + positions)  %.1f Gbp/s  runs=%d" % (n_reads * L / dt / 1e9, n), flush=True)
