@@ -20,6 +20,8 @@ __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
     uint8_t *__restrict__ o_hpc, uint32_t *__restrict__ o_pos, uint64_t capacity) {
     __shared__ uint32_t starts[HS_SEG / 32]; // bit i: a non-empty read starts at seg + i
     __shared__ uint32_t ls[HS_THREADS], lm[HS_THREADS];
+    __shared__ uint32_t out_p[HS_SEG];
+    __shared__ uint8_t out_b[HS_SEG];
     __shared__ uint64_t sh_r, sh_g, sh_start;
     const int t = threadIdx.x;
     const uint64_t seg = (uint64_t)blockIdx.x * HS_SEG, seg_end = seg + HS_SEG;
@@ -102,18 +104,26 @@ __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
         }
         __syncthreads();
     }
-    uint64_t slot = sh_g + (t ? ls[t - 1] : 0u);
+    // compact into LDS first, then write whole lines: the outputs of a segment are one contiguous range
+    uint32_t slot = t ? ls[t - 1] : 0u; // segment-relative
+    const uint32_t total = ls[HS_THREADS - 1];
     const uint32_t carry = t ? lm[t - 1] : 0u;
     uint64_t cur = carry ? seg + carry - 1 : sh_start; // start of the read the current byte belongs to
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         if ((sb >> j) & 1) cur = q0 + j;
         if ((heads >> j) & 1) {
-            if (slot < capacity) {
-                if (o_hpc) o_hpc[slot] = (uint8_t)c[j];
-                if (o_pos) o_pos[slot] = (uint32_t)(q0 + j - cur);
-            }
+            out_b[slot] = (uint8_t)c[j];
+            out_p[slot] = (uint32_t)(q0 + j - cur);
             slot++;
+        }
+    }
+    __syncthreads();
+    const uint64_t g = sh_g;
+    for (uint32_t i = t; i < total; i += HS_THREADS) {
+        if (g + i < capacity) {
+            if (o_hpc) o_hpc[g + i] = out_b[i];
+            if (o_pos) o_pos[g + i] = out_p[i];
         }
     }
 }
