@@ -1,3 +1,5 @@
+// Experiment kept for reference: semantics of global_load_lds_dwordx4 on gfx950 -- lane i of a load lands at
+// LDS base + instruction offset + 16 i, also under a partial EXEC mask.  Build: hipcc -O3 --offload-arch=gfx950 -o t lds_direct_test.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
