@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLD
-from gpu_util import OMODE, compare, pkg, rand_read
+from gpu_util import FIELDS, OMODE, compare, pkg, rand_read
 
 pytestmark = pytest.mark.gpu
 HM = pkg.HashMode
@@ -538,3 +538,37 @@ def test_device_api_streams_timing_and_minimizer_capacity(eng, oracle):
     assert (t["hash"].cpu().numpy().view(np.uint64) == ref["hash"]).all()
     assert (t["mn_j"].cpu().numpy().view(np.uint32)[: nm // 3] == rm["j"][: nm // 3]).all()
     e2.close()
+
+
+def test_contexts_are_independent_across_threads(oracle):
+    """include/s2k.h: one s2k_ctx per (thread, device), contexts are independent -- the shape of the reference's
+    parallel_fastx workers (src/main.rs:65-79), each with its own engine, running at the same time."""
+    import threading
+
+    rng = np.random.default_rng(51)
+    jobs = []
+    for i in range(4):
+        reads = [rand_read(rng, int(n), hp=0.2) for n in rng.integers(0, 40000, size=30)]
+        mode = (HM.Regular, HM.Hpc, HM.Simd, HM.HpcSimd)[i]
+        bases, off = pkg.pack_reads(reads)
+        jobs.append((bases, off, mode, oracle.batch(bases, off, 31, 6, 0.02, OMODE[mode])))
+    errors = []
+
+    def work(job):
+        try:
+            bases, off, mode, ref = job
+            e = pkg.Engine(0)
+            for _ in range(5):
+                got = e.extract(bases, off, 31, 6, 0.02, mode)
+                for f in FIELDS:
+                    assert (got[f] == ref[f]).all(), (int(mode), f)
+            e.close()
+        except Exception as ex:  # noqa: BLE001 - reported to the main thread
+            errors.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
