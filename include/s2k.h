@@ -135,7 +135,9 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
                        const s2k_params *params, s2k_result *out);
 void s2k_result_free(s2k_result *res);
 
-/* Same computation with inputs and outputs resident in HBM.  Enqueued on the context's stream; if
+/* Same computation with inputs and outputs resident in HBM: d_read_off[0] must be 0 and d_read_off[n_reads] ==
+ * n_bases (read r = d_bases[d_read_off[r] .. d_read_off[r+1])); a d_bases pointer that is not 16-byte aligned is
+ * accepted but takes the slower read-serial kernels.  Enqueued on the context's stream; if
  * `counts` is non-NULL the call waits for completion and fills it (and returns S2K_ERR_CAPACITY if
  * an output capacity was too small -- counts then hold the required sizes).  With counts == NULL the
  * call returns after enqueueing; s2k_sync() later waits and reports the same status/counts. */
@@ -145,7 +147,8 @@ s2k_status s2k_extract_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64
 s2k_status s2k_sync(s2k_ctx *ctx, s2k_counts *counts);
 
 /* ---- standalone homopolymer compression (src/hpc.rs:28-41 hpc, :44-147 encode_rle_simd) ---------- */
-/* Per read: compressed string + run-start positions (read-relative).  d_hpc_off: n_reads+1 prefix of
+/* Per read: compressed string + run-start positions (read-relative); same layout rules as s2k_extract_device.
+ * d_hpc_off: n_reads+1 prefix of
  * run counts; d_hpc / d_pos (either may be NULL) receive up to `capacity` entries. */
 s2k_status s2k_hpc_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
                           uint64_t n_bases, uint64_t *d_hpc_off, uint8_t *d_hpc, uint32_t *d_pos,
