@@ -172,7 +172,7 @@ def main():
 
     # ---- CPU baseline: the oracle = scalar port of the reference, on this host's cores --------------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only (the host cores are shared by all ranks)
         from oracle import s2k_oracle as so
 
         orc = so.Oracle(native=True)  # -O3 -march=native, like the reference's -Ctarget-cpu=native (.cargo/config:2)
