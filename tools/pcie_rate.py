@@ -3,11 +3,16 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from s2k_loader import import_package
-from oracle import s2k_oracle as so
+import torch
 pkg = import_package()
 eng = pkg.Engine(0)
 n_reads, rl = int(os.environ.get('S2K_PCIE_READS', 400_000)), 10_000
-bases = so.get().synth_bases(1, 0, n_reads * rl)
+_d = torch.empty(n_reads * rl + 64, dtype=torch.uint8, device="cuda:0")
+torch.cuda.synchronize()
+eng.synth_bases_device(1, 0, n_reads * rl, _d.data_ptr())  # the library's own generator; the input is then moved to pageable host memory
+eng.lib.s2k_sync(eng.ctx, None)
+bases = _d[: n_reads * rl].cpu().numpy().copy()
+del _d
 off = np.arange(n_reads + 1, dtype=np.uint64) * rl
 import ctypes as C
 def c_extract(mode):  # the C call alone (what a Rust/C++ caller pays), no numpy conversion of the result
