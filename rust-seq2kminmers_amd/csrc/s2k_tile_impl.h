@@ -617,8 +617,11 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                     if (lane == 0) pstart = chunk_prev;
                     if ((internal || (external && lane == first_ext)) && bpos != ~0ull) {
                         const uint32_t Rr = sem.read_runs[(uint64_t)r0 + c0 + lane]; // lane holds the end of that read
-                        if (bpos - pstart <= (uint64_t)l) wextra = 1;              // seq.len() <= l yields nothing (src/lib.rs:97)
-                        else if (Rr >= l) {
+                        if (bpos - pstart <= (uint64_t)l) {
+                            // seq.len() <= l yields nothing (src/lib.rs:97).  Only a read of exactly l distinct bases has a
+                            // window that survives the l-1 clear; a shorter one must not reach back into its predecessor.
+                            wextra = Rr >= l ? 1u : 0u;
+                        } else if (Rr >= l) {
                             const uint32_t sentinel = Rr - l + 1;
                             if (sentinel >= 32 && (sentinel & 15) == 0) wextra = 16;
                         }
