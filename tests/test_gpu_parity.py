@@ -489,6 +489,28 @@ def test_fuzz_random_batches(eng, oracle):
             compare(eng, oracle, reads, l, k, d, mode, expect_path=0, tag="fuzz%d" % it)
 
 
+def test_fuzz_many_tiny_reads(eng, oracle):
+    """hundreds of read starts per 9216-base tile (more than the per-tile boundary lists hold), all four modes:
+    lengths around l, around the 16-block tail rule of the Simd modes, empty reads in between."""
+    rng = np.random.default_rng(int(os.environ.get("S2K_FUZZ_SEED", 7)))
+    for it in range(int(os.environ.get("S2K_FUZZ_ITERS", 24))):
+        l = int(rng.choice([4, 7, 12, 15, 31]))
+        k = int(rng.choice([1, 2, 4]))
+        d = float(rng.choice([0.05, 0.3, 1.0]))
+        n_reads = int(rng.integers(200, 1500))
+        kinds = rng.integers(0, 5, size=n_reads)
+        lens = np.where(kinds == 0, 0,
+               np.where(kinds == 1, l + rng.integers(-2, 3, size=n_reads),
+               np.where(kinds == 2, l - 1 + 16 * rng.integers(1, 6, size=n_reads) + rng.integers(-1, 2, size=n_reads),
+               np.where(kinds == 3, rng.integers(1, 60, size=n_reads), rng.integers(60, 300, size=n_reads)))))
+        hp = float(rng.choice([0.0, 0.3]))
+        reads = [rand_read(rng, int(max(0, n)), hp=hp, odd=0.01) for n in lens]
+        if it % 3 == 0:
+            reads.insert(len(reads) // 2, rand_read(rng, 30000, hp=hp))  # a long read among them
+        for mode in SCALAR + (HM.Simd, HM.HpcSimd):
+            compare(eng, oracle, reads, l, k, d, mode, expect_path=0, tag="tiny%d" % it)
+
+
 def test_device_api_streams_timing_and_minimizer_capacity(eng, oracle):
     """s2k_set_stream with a non-default torch stream, HIP-event timing totals, minimizer-triple capacity."""
     import torch
