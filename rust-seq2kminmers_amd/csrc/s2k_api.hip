@@ -227,7 +227,6 @@ s2k_status enqueue(s2k_ctx *ctx) {
         a.off = 0;
         mn_cnt = a.take<uint32_t>(n_reads + 1);
         mn_off = o.mn_off ? o.mn_off : a.take<uint64_t>(n_reads + 1);
-        if (o.mn_off) (void)0;
         scan_tmp = a.take<uint64_t>(scan_tmp_bytes(n_reads > n_tiles ? n_reads : n_tiles) / sizeof(uint64_t) + 1);
         pool_cursor = a.take<uint64_t>(4);
         if (!c.serial) {
@@ -566,9 +565,7 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
     S2K_TRY(hipStreamSynchronize(ctx->stream), "H2D sync");
 
     const bool want_mn = params->flags & S2K_FLAG_WANT_MINIMIZERS;
-    const bool serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(sem);
     uint64_t cap = pool_estimate(n_bases, n_reads, params->density, sem.hpc);
-    (void)serial;
     s2k_counts cnt;
     s2k_device_out o;
     for (int attempt = 0;; attempt++) {
