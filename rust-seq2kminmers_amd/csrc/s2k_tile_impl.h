@@ -723,7 +723,11 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                     const uint32_t keep = v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
                     c += __popc(vm[d] & keep);
                 }
-                below = bcast(wave_incl_scan(c, lane), 63);
+                // lanes left of the boundary's lane count everything, lanes right of it nothing: the total is the
+                // exclusive offset of that lane plus its own share -- one v_readlane instead of a wave scan
+                const int hbi = S.hb[i];
+                const int lb = hbi <= 0 ? 0 : ((uint32_t)hbi >= Tq * 64u ? 63 : (int)__umulhi((uint32_t)hbi, rcpTq));
+                below = bcast(myoff + c, lb);
             }
             if ((uint32_t)lane == i) mine = below - below_prev;
             below_prev = below;
