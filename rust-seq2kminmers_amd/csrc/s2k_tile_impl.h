@@ -833,13 +833,11 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 if (act[u]) {
                     if constexpr (HPC) {
                         uint32_t rp = 0, re = 0;
-                        if (sem.end_kind == 2) { // HpcSimd: start of the last run, st[p+l-1] (src/nthash_hpc_simd.rs:64)
-                            hpc_rawpos2(S, x[u], l - 1, nh, halo_n, Tq, rcpTq, rp, re);
-                            e1[u] = t0 + re;
-                        } else {
-                            hpc_rawpos2(S, x[u], l, nh, halo_n, Tq, rcpTq, rp, re); // head x + l exists: the hit survived validation
-                            e1[u] = t0 + re - 1; // st[p+l] - 1, src/nthash_hpc.rs:281
-                        }
+                        // Hpc: st[p+l] - 1 (src/nthash_hpc.rs:281; head x + l exists: the hit survived validation);
+                        // HpcSimd: st[p+l-1], the start of the last run (src/nthash_hpc_simd.rs:64)
+                        const uint32_t back = sem.end_kind == 2 ? 1u : 0u;
+                        hpc_rawpos2(S, x[u], l - back, nh, halo_n, Tq, rcpTq, rp, re);
+                        e1[u] = t0 + re - (1u - back);
                         p[u] = t0 + rp;
                     } else {
                         p[u] = t0 + x[u];
