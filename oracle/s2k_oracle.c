@@ -757,6 +757,7 @@ uint64_t s2k_oracle_batch(const uint8_t *bases, const uint64_t *off, uint64_t n_
  * out = { n_minimizers, n_kminmers, XOR hash, SUM start, SUM end, #rev }.
  * ---------------------------------------------------------------------------------------- */
 struct sum_job {
+    const uint64_t *off; /* NULL: reads of read_len bases each; else read r = stream [off[r], off[r+1]) */
     uint64_t seed, r0, r1, read_len;
     unsigned l, k;
     uint32_t bound;
@@ -766,15 +767,20 @@ struct sum_job {
 
 static void *sum_worker(void *p) {
     struct sum_job *jb = (struct sum_job *)p;
-    uint8_t *buf = (uint8_t *)malloc(jb->read_len + 1);
-    size_t ocap = jb->read_len + 1, scap = 0;
+    uint64_t maxlen = jb->read_len;
+    if (jb->off)
+        for (uint64_t r = jb->r0; r < jb->r1; r++)
+            if (jb->off[r + 1] - jb->off[r] > maxlen) maxlen = jb->off[r + 1] - jb->off[r];
+    uint8_t *buf = (uint8_t *)malloc(maxlen + 1);
+    size_t ocap = maxlen + 1, scap = 0;
     uint64_t *h = (uint64_t *)malloc(ocap * 8), *st = (uint64_t *)malloc(ocap * 8), *en = (uint64_t *)malloc(ocap * 8);
     uint8_t *rv = (uint8_t *)malloc(ocap);
     uint64_t *scratch = NULL;
     for (uint64_t r = jb->r0; r < jb->r1; r++) {
-        s2k_oracle_synth_bases(jb->seed, r * jb->read_len, jb->read_len, buf);
-        size_t M = s2k_oracle_minimizers(buf, jb->read_len, jb->l, jb->bound, jb->mode, NULL, NULL, NULL, 0);
-        size_t c = kminmers_one(buf, jb->read_len, jb->l, jb->k, jb->bound, jb->mode, h, st, en, rv, ocap, &scratch, &scap);
+        const uint64_t a = jb->off ? jb->off[r] : r * jb->read_len, n = jb->off ? jb->off[r + 1] - a : jb->read_len;
+        s2k_oracle_synth_bases(jb->seed, a, n, buf);
+        size_t M = s2k_oracle_minimizers(buf, n, jb->l, jb->bound, jb->mode, NULL, NULL, NULL, 0);
+        size_t c = kminmers_one(buf, n, jb->l, jb->k, jb->bound, jb->mode, h, st, en, rv, ocap, &scratch, &scap);
         jb->out[0] += M;
         jb->out[1] += c;
         for (size_t i = 0; i < c; i++) {
@@ -788,8 +794,21 @@ static void *sum_worker(void *p) {
     return NULL;
 }
 
+static void synth_checksums_impl(uint64_t seed, const uint64_t *off, uint64_t n_reads, uint64_t read_len, unsigned l,
+                                 unsigned k, double density, int mode, int threads, uint64_t out[6]);
+
 void s2k_oracle_synth_checksums(uint64_t seed, uint64_t n_reads, uint64_t read_len, unsigned l, unsigned k,
                                 double density, int mode, int threads, uint64_t out[6]) {
+    synth_checksums_impl(seed, NULL, n_reads, read_len, l, k, density, mode, threads, out);
+}
+
+void s2k_oracle_synth_checksums_off(uint64_t seed, const uint64_t *off, uint64_t n_reads, unsigned l, unsigned k,
+                                    double density, int mode, int threads, uint64_t out[6]) {
+    synth_checksums_impl(seed, off, n_reads, 0, l, k, density, mode, threads, out);
+}
+
+static void synth_checksums_impl(uint64_t seed, const uint64_t *off, uint64_t n_reads, uint64_t read_len, unsigned l,
+                                 unsigned k, double density, int mode, int threads, uint64_t out[6]) {
     tables();
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > n_reads) threads = n_reads ? (int)n_reads : 1;
@@ -797,6 +816,7 @@ void s2k_oracle_synth_checksums(uint64_t seed, uint64_t n_reads, uint64_t read_l
     pthread_t *th = (pthread_t *)malloc(sizeof(*th) * threads);
     for (int t = 0; t < threads; t++) {
         jobs[t].seed = seed;
+        jobs[t].off = off;
         jobs[t].r0 = n_reads * (uint64_t)t / threads;
         jobs[t].r1 = n_reads * (uint64_t)(t + 1) / threads;
         jobs[t].read_len = read_len;

@@ -104,6 +104,10 @@ void s2k_oracle_synth_bases(uint64_t seed, uint64_t first_base, uint64_t n, uint
 void s2k_oracle_synth_checksums(uint64_t seed, uint64_t n_reads, uint64_t read_len, unsigned l, unsigned k,
                                 double density, int mode, int threads, uint64_t out[6]);
 
+/* Same for ragged reads: read r = synth stream [off[r], off[r+1]). */
+void s2k_oracle_synth_checksums_off(uint64_t seed, const uint64_t *off, uint64_t n_reads, unsigned l, unsigned k,
+                                    double density, int mode, int threads, uint64_t out[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,9 @@ class Oracle:
         L.s2k_oracle_synth_checksums.restype = None
         L.s2k_oracle_synth_checksums.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_uint, C.c_double,
                                                  C.c_int, C.c_int, _u64p]
+        L.s2k_oracle_synth_checksums_off.restype = None
+        L.s2k_oracle_synth_checksums_off.argtypes = [C.c_uint64, _u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_double,
+                                                     C.c_int, C.c_int, _u64p]
 
     # -- scalars ---------------------------------------------------------------------------
     def hash_bound(self, d):
@@ -200,6 +203,13 @@ class Oracle:
         """whole-run checksums of a synthetic batch generated read by read (no big host buffer)"""
         out = np.zeros(6, dtype=np.uint64)
         self.lib.s2k_oracle_synth_checksums(seed, n_reads, read_len, l, k, density, mode, threads, _ptr(out, _u64p))
+        return dict(zip(("n_minimizers", "n_kminmers", "xor_hash", "sum_start", "sum_end", "n_rev"), map(int, out)))
+
+    def synth_checksums_off(self, seed, off, l, k, density, mode, threads=1):
+        """as synth_checksums for ragged reads: read r = synthetic stream [off[r], off[r+1])"""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        out = np.zeros(6, dtype=np.uint64)
+        self.lib.s2k_oracle_synth_checksums_off(seed, _ptr(off, _u64p), len(off) - 1, l, k, density, mode, threads, _ptr(out, _u64p))
         return dict(zip(("n_minimizers", "n_kminmers", "xor_hash", "sum_start", "sum_end", "n_rev"), map(int, out)))
 
     def batch_minimizers(self, bases, off, l, density, mode):

@@ -404,6 +404,45 @@ def test_full_size_config2_whole_run_checksums(eng, oracle):
         assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"]
 
 
+def test_full_size_config3_shard_whole_run_checksums(eng, oracle):
+    """BASELINE config 3 at the size ONE GPU holds when 8 share the 200 Gbp: ~25 Gbp of ONT-like reads (lengths
+    lognormal, mean 20 kbp, sigma 0.5, clipped to [1 k, 200 k]), l=31 k=10 d=0.01, both scalar modes; every k-min-mer
+    folded into count / XOR / SUM(start) / SUM(end) / #rev and compared with the oracle run on the host cores."""
+    import os
+    import torch
+
+    rng = np.random.default_rng(303)
+    lens = _lognormal_lengths(rng, 1_250_000, 20000, 0.5, 1000, 200000)
+    off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+    n_reads, n_bases = len(lens), int(off[-1])
+    dev = torch.device("cuda", 0)
+    d_b = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
+    d_o = torch.from_numpy(off.astype(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    eng.synth_bases_device(3, 0, n_bases, d_b.data_ptr())
+    cap = int(n_bases * 0.0215)
+    t = {"km_off": torch.empty(n_reads + 1, dtype=torch.int64, device=dev), "hash": torch.empty(cap, dtype=torch.int64, device=dev),
+         "start": torch.empty(cap, dtype=torch.int32, device=dev), "end": torch.empty(cap, dtype=torch.int32, device=dev),
+         "rev": torch.empty(cap, dtype=torch.uint8, device=dev)}
+    o = pkg.DeviceOut()
+    o.km_capacity = cap
+    o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    for mode in SCALAR:
+        torch.cuda.synchronize()
+        c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, 31, 10, 0.01, int(mode), o)
+        ref = oracle.synth_checksums_off(3, off, 31, 10, 0.01, OMODE[mode], threads=threads)
+        n = c["n_kminmers"]
+        assert c["path"] == 0 and c["n_bases"] == n_bases and n_bases > 24_000_000_000
+        assert (n, c["n_minimizers"], c["xor_hash"]) == (ref["n_kminmers"], ref["n_minimizers"], ref["xor_hash"]), (int(mode), c, ref)
+        assert _xor_reduce(t["hash"][:n]) == ref["xor_hash"]
+        assert int(t["start"][:n].to(torch.int64).sum().item()) == ref["sum_start"]
+        assert int(t["end"][:n].to(torch.int64).sum().item()) == ref["sum_end"]
+        assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"]
+    del d_b, t
+    torch.cuda.empty_cache()
+
+
 def _lognormal_lengths(rng, n, mean, sigma, lo, hi):
     mu = np.log(mean) - sigma * sigma / 2
     return np.clip(rng.lognormal(mu, sigma, size=n), lo, hi).astype(np.int64)

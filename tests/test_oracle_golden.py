@@ -234,3 +234,16 @@ def test_synth_checksums_equal_materialised_batch(oracle):
         assert cs["sum_end"] == int(ref["end"].astype(np.uint64).sum())
         assert cs["n_rev"] == int(ref["rev"].sum())
         assert cs["n_minimizers"] == int(oracle.batch_minimizers(bases, off, 31, 0.01, mode)["n"])
+
+
+def test_synth_checksums_ragged_equal_materialised_batch(oracle):
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 5000, size=41)
+    off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+    bases = oracle.synth_bases(9, 0, int(off[-1]))
+    for mode in (0, 1):
+        ref = oracle.batch(bases, off, 31, 10, 0.01, mode, threads=2)
+        cs = oracle.synth_checksums_off(9, off, 31, 10, 0.01, mode, threads=3)
+        assert cs["n_kminmers"] == ref["n"] > 0 and cs["xor_hash"] == int(np.bitwise_xor.reduce(ref["hash"]))
+        assert cs["sum_start"] == int(ref["start"].astype(np.uint64).sum()) and cs["sum_end"] == int(ref["end"].astype(np.uint64).sum())
+        assert cs["n_rev"] == int(ref["rev"].sum())
