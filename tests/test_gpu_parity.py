@@ -464,7 +464,7 @@ def test_baseline_config4_hifi_like_hpc_backmap(eng, oracle):
     checked against the oracle."""
     rng = np.random.default_rng(32)
     reads = []
-    for _ in range(60):
+    for _ in range(1500):  # 22 Mbp, every tuple compared
         n = int(max(2000, rng.normal(15000, 2000)))
         runs = rng.geometric(0.5, size=n)  # mean run length 2
         stretch = rng.random(n) < 0.001
@@ -486,6 +486,38 @@ def test_baseline_config5_mbp_contigs_sparse_density(eng, oracle):
     for mode in SCALAR:
         got = compare(eng, oracle, reads, 31, 10, 0.001, mode, expect_path=0, tag="C5-contigs")
         assert got["counts"]["hash_bound"] == 4294967
+
+
+def test_full_size_config5_whole_run_checksums(eng, oracle):
+    """BASELINE config 5 at its full size: 1000 contigs of 1 Mbp, d = 0.001, both scalar modes, whole-run checksums."""
+    import os
+    import torch
+
+    n_reads, L, seed = 1000, 1_000_000, 5
+    dev = torch.device("cuda", 0)
+    d_b = torch.empty(n_reads * L + 64, dtype=torch.uint8, device=dev)
+    d_o = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L
+    torch.cuda.synchronize()
+    eng.synth_bases_device(seed, 0, n_reads * L, d_b.data_ptr())
+    cap = int(n_reads * L * 0.003) + 4096
+    t = {"km_off": torch.empty(n_reads + 1, dtype=torch.int64, device=dev), "hash": torch.empty(cap, dtype=torch.int64, device=dev),
+         "start": torch.empty(cap, dtype=torch.int32, device=dev), "end": torch.empty(cap, dtype=torch.int32, device=dev),
+         "rev": torch.empty(cap, dtype=torch.uint8, device=dev)}
+    o = pkg.DeviceOut()
+    o.km_capacity = cap
+    o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    for mode in SCALAR:
+        torch.cuda.synchronize()
+        c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_reads * L, 31, 10, 0.001, int(mode), o)
+        ref = oracle.synth_checksums(seed, n_reads, L, 31, 10, 0.001, OMODE[mode], threads=threads)
+        n = c["n_kminmers"]
+        assert c["path"] == 0 and c["hash_bound"] == 4294967
+        assert (n, c["n_minimizers"], c["xor_hash"]) == (ref["n_kminmers"], ref["n_minimizers"], ref["xor_hash"]), (int(mode), c, ref)
+        assert _xor_reduce(t["hash"][:n]) == ref["xor_hash"]
+        assert int(t["start"][:n].to(torch.int64).sum().item()) == ref["sum_start"]
+        assert int(t["end"][:n].to(torch.int64).sum().item()) == ref["sum_end"]
+        assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"]
 
 
 def test_degenerate_batches(eng, oracle):
