@@ -171,7 +171,8 @@ s2k_status s2k_timing_total(s2k_ctx *ctx, int which, double *ms_sum, uint32_t *n
  * KminmersIterator per record (src/main.rs:51-83).  Records are parsed on the host into batches
  * (bases back to back + read_off) held in pinned memory, so a batch is what s2k_extract consumes. */
 typedef struct s2k_fastx s2k_fastx; /* opaque reader */
-/* Opens a FASTA (multi-line allowed) or FASTQ (4-line) file; the format is detected from the first byte. */
+/* Opens a plain (uncompressed) FASTA (multi-line allowed) or FASTQ (4-line) file; the format is detected from the
+ * first non-blank byte. */
 s2k_fastx *s2k_fastx_open(const char *path, s2k_status *status);
 /* Parses the next records until `max_bases` bases or `max_reads` reads are collected (at least one record).
  * *bases / *read_off point into reader-owned buffers, valid until the next call; *n_reads == 0 at end of file. */
