@@ -56,7 +56,8 @@ constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window s
 constexpr int CAPP = 16;                               // positions per capture piece
 constexpr int NPC = TILE_T / CAPP;                     // 9 capture pieces per lane
 constexpr int MAX_L_TILED = 64;
-constexpr int LISTCAP = 512;                           // hits handled per dense batch
+constexpr int LISTCAP = 256;                           // hits handled per dense batch
+constexpr int JOBCAP = 32;                             // queued hash re-derivations per flush
 constexpr int REG_LA = 2;
 constexpr int HPC_LA = 2;                              // seed look-ahead (positions) of the Hpc hash loop: 8 spills there
 constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
@@ -72,18 +73,16 @@ struct NoHpcLds {};
 template <bool HPC>
 struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
     uint8_t buf[BUF_BYTES];
-    uint32_t caps[NPC][64];  // hash of the last hit of each 16-position piece
-    uint32_t hm[64][5];      // raw hit masks, bit x = lane-local hash position x (stored bytewise)
-    uint16_t list[LISTCAP];  // validated hits of the current batch, tile-local hash positions, ascending
-    uint16_t jobx[64];       // hits whose hash must be re-derived: tile-local position ...
-    uint32_t jobslot[64];    // ... and record slot (relative to the tile's base)
-    int32_t hb[64];          // read starts inside the tile, as hash-space positions (ascending)
+    uint16_t list[LISTCAP];  // validated hits of the current batch: tile-local hash position (bits 0-13), ascending; bit 15 = hash must be re-derived
+    uint16_t jobx[JOBCAP];   // hits whose hash must be re-derived: tile-local position ...
+    uint32_t jobslot[JOBCAP];// ... and record slot (relative to the tile's base)
+    int16_t hb[64];          // read starts inside the tile, as hash-space positions (ascending; 0 .. TILE_BASES)
     uint64_t rs[64];         // rs[i] = read_off[r0 + i]
 };
 constexpr int TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c], l-1)};  OUT table at 2048: {rotl(h[c], l), rotr(rc[c], 1)}
 template <bool HPC>
 constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>); }
-static_assert(2 * block_lds_bytes<true>() <= 160 * 1024, "two blocks per CU must fit the 160 KiB LDS");
+static_assert(3 * block_lds_bytes<true>() <= 160 * 1024, "three blocks per CU must fit the 160 KiB LDS");
 
 // inclusive scan over the 64 lanes with DPP row shifts / broadcasts (no LDS round trips)
 __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -166,9 +165,14 @@ __device__ __forceinline__ uint2 tab_in(const uint2 *tab, uint32_t c) { return t
 __device__ __forceinline__ uint2 tab_out(const uint2 *tab, uint32_t c) { return tab[256 + c]; }
 
 // ------------------------------------------------------------------------------------------------
-// Hash loop, compile-time l, NP 16-byte pieces per lane.  Lane q owns hash positions
-// [16*NP*q, 16*NP*(q+1)) of the byte array D (LDS).  Branch-free: per position
+// Hash loop, compile-time l.  Lane q owns hash positions [Tq*q, Tq*(q+1)), Tq = 16*np (np odd: the lane
+// stride is then an odd number of 16 B pieces and the piece reads are bank-conflict free), of the byte array D
+// (LDS).  Branch-free per position:
 //   hv = min(fh, rh); hit = hv <= bound; cap = hit ? hv : cap; bits = bits<<1 | hit; roll.
+// Everything the dense phase needs stays in REGISTERS: `raw[w]` = hit bits of positions 32w .. 32w+31 of the lane,
+// `caps[g]` = hash of the last hit of the 16-position piece g.  (Round 1 kept both in LDS plus one LDS address per base
+// of the window in registers: 256 VGPRs and 19 KB of LDS per wave, i.e. two waves per SIMD.  With the next tile's
+// staging loads issued after the hash loop instead of before it, the address history fits three waves per SIMD.)
 // ------------------------------------------------------------------------------------------------
 // One position of the hot loop.  The hit test, the capture of the hit's hash and the hit bit are three
 // VALU instructions chained through VCC (compare -> select -> add-with-carry shifts the bit in).
@@ -180,33 +184,43 @@ __device__ __forceinline__ void hit_track(uint32_t hv, uint32_t bound, uint32_t 
         : "s"(bound), "v"(hv)
         : "vcc");
 }
+// hit bits of a finished piece -> raw[]: `bits` holds position 32w at its highest used bit
+template <int P>
+__device__ __forceinline__ void close_piece(uint32_t &bits, uint32_t (&raw)[5]) {
+    if constexpr (P % 32 == 15) raw[P / 32] = __builtin_bitreverse32(bits) >> 16; // first half of the word (final if the loop ends here)
+    if constexpr (P % 32 == 31) {
+        raw[P / 32] = __builtin_bitreverse32(bits);
+        bits = 0;
+    }
+}
 
 // Step s of the lane's stream (s = 0 .. T+L-1, all compile-time): base s enters the window; for s >= L the
 // l-mer at position p = s - L is complete, so it is tested and then rolled forward with OUT[p], IN[s].
-template <int L, int T, int LA, int S, class WL>
-__device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], uint32_t (&A)[T + L], uint2 (&EI)[T + L],
-                                           uint2 (&EO)[T], uint32_t &fh, uint32_t &rh, uint32_t &cap, uint32_t &bits,
-                                           uint32_t bound, uint8_t *hmb, WL &Sx, int lane) {
+// W[] holds the lane's stream as dwords (piece j = W[4j .. 4j+3], read one piece ahead of its first use); only the
+// ~12 dwords between the outgoing and the incoming base are live at any time.
+template <int L, int T, int LA, int S>
+__device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * ((T + L + 15) / 16)], uint32_t (&A)[T + L],
+                                           uint2 (&EI)[T + L], uint2 (&EO)[T], uint32_t &fh, uint32_t &rh, uint32_t (&caps)[NPC], uint32_t (&raw)[5],
+                                           uint32_t &bits, uint32_t bound, int np) {
     if constexpr (S < T + L - 1) {
-        // seeds are fetched 8 steps ahead of their use, a group of 8 at a time
+        if constexpr (S % 16 == 0 && S / 16 + 2 < (T + L + 15) / 16) { // piece S/16+2: its first base enters >= 16 steps from now
+            const uint4 v = src[S / 16 + 2];
+            W[4 * (S / 16 + 2)] = v.x; W[4 * (S / 16 + 2) + 1] = v.y; W[4 * (S / 16 + 2) + 2] = v.z; W[4 * (S / 16 + 2) + 3] = v.w;
+        }
+        // seeds are fetched LA steps ahead of their use, a group of LA at a time
         if constexpr (S % LA == 0) {
+            __builtin_amdgcn_sched_barrier(0); // keep the scheduler from hoisting later groups' look-ups (register pressure)
             constexpr int G = S + LA; // first base of the group entering LA steps from now
-            if constexpr (G % 16 == 0 && G > 0) { // the group starts a new 16-byte piece: slide the 32-byte window
-                W[0] = W[4]; W[1] = W[5]; W[2] = W[6]; W[3] = W[7];
-                const uint4 v = src[G / 16 + 1];
-                W[4] = v.x; W[5] = v.y; W[6] = v.z; W[7] = v.w;
-            }
-            constexpr int WB = (G % 16); // offset of the group inside the window
-#define S2K_IN(J)                                                          \
+#define S2K_IN(J)                                                        \
     if constexpr (J < LA && G + J < T + L - 1) {                          \
-        A[G + J] = byte_x8<(WB + J) & 3>(W[(WB + J) >> 2]);                \
+        A[G + J] = byte_x8<(G + J) & 3>(W[(G + J) >> 2]);                  \
         EI[G + J] = seed_pair<0>(A[G + J]);                                \
     }
             S2K_IN(0) S2K_IN(1) S2K_IN(2) S2K_IN(3) S2K_IN(4) S2K_IN(5) S2K_IN(6) S2K_IN(7)
 #undef S2K_IN
             constexpr int H = S + LA - L; // first base of the group leaving LA steps from now
-#define S2K_OUT(J)                                                         \
-    if constexpr (J < LA && H + J >= 0 && H + J < T - 1) EO[H + J] = seed_pair<2048>(A[H + J]);
+#define S2K_OUT(J) \
+    if constexpr (J < LA && H + J >= 0 && H + J < T - 1) EO[H + J] = seed_pair<2048>(A[H + J]); // offset formed l positions ago
             S2K_OUT(0) S2K_OUT(1) S2K_OUT(2) S2K_OUT(3) S2K_OUT(4) S2K_OUT(5) S2K_OUT(6) S2K_OUT(7)
 #undef S2K_OUT
         }
@@ -216,51 +230,49 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[8], u
         } else {
             constexpr int P = S - L;
             const uint32_t hv = fh < rh ? fh : rh;                              // canonical (src/nthash_hpc.rs:276)
-            hit_track(hv, bound, cap, bits);                                    // hv <= bound (src/nthash_hpc.rs:277 / src/lib.rs:228)
+            hit_track(hv, bound, caps[P / CAPP], bits);                         // hv <= bound (src/nthash_hpc.rs:277 / src/lib.rs:228)
             fh = __builtin_rotateleft32(fh, 1) ^ EO[P].x ^ EI[S].x;             // src/nthash_hpc.rs:245
             rh = __builtin_rotateright32(rh, 1) ^ EO[P].y ^ EI[S].y;            // src/nthash_hpc.rs:247-249
-            if constexpr (P % 8 == 7) {
-                hmb[P / 8] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-                if constexpr (P % CAPP == CAPP - 1) Sx.caps[P / CAPP][lane] = cap;
-                bits = 0;
+            if constexpr (P % 16 == 15) {
+                close_piece<P>(bits, raw);
+                if (P / 16 + 1 >= np) return; // wave-uniform: the (compacted) tile is shorter than 144 bases per lane
             }
         }
-        hash_steps<L, T, LA, S + 1>(src, W, A, EI, EO, fh, rh, cap, bits, bound, hmb, Sx, lane);
+        hash_steps<L, T, LA, S + 1>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
     } else { // last position: test only, nothing left to roll into
         const uint32_t hv = fh < rh ? fh : rh;
-        hit_track(hv, bound, cap, bits);
-        hmb[(T - 1) / 8] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-        Sx.caps[(T - 1) / CAPP][lane] = cap;
+        hit_track(hv, bound, caps[(T - 1) / CAPP], bits);
+        close_piece<T - 1>(bits, raw);
     }
 }
 
-template <int L, int NP, int LA, class WL>
-__device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t bound, int lane, WL &S) {
-    constexpr int T = 16 * NP;
+template <int L, int LA>
+__device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t bound, int lane, int np, uint32_t (&caps)[NPC],
+                                                 uint32_t (&raw)[5]) {
+    constexpr int T = TILE_T;
     static_assert(L >= 9 && L <= 32, "the static schedule assumes 8 < l <= 32");
-    uint32_t W[8]; // 32-byte window over the lane's stream: pieces i, i+1
-    const uint4 *src = reinterpret_cast<const uint4 *>(D + T * lane);
+    static_assert(CAPP == 16 && LA <= 8, "pieces of 16 positions");
+    uint32_t W[4 * ((T + L + 15) / 16)];
+    const uint4 *src = reinterpret_cast<const uint4 *>(D + 16 * np * lane);
     {
         const uint4 v0 = src[0], v1 = src[1];
         W[0] = v0.x; W[1] = v0.y; W[2] = v0.z; W[3] = v0.w;
         W[4] = v1.x; W[5] = v1.y; W[6] = v1.z; W[7] = v1.w;
     }
-    uint32_t A[T + L];
+    uint32_t A[T + L]; // LDS byte offset of each base's table entries: formed when the base enters, reused when it leaves
     uint2 EI[T + L], EO[T];
     A[0] = byte_x8<0>(W[0]); A[1] = byte_x8<1>(W[0]); A[2] = byte_x8<2>(W[0]); A[3] = byte_x8<3>(W[0]);
     if constexpr (LA > 4) { A[4] = byte_x8<0>(W[1]); A[5] = byte_x8<1>(W[1]); A[6] = byte_x8<2>(W[1]); A[7] = byte_x8<3>(W[1]); }
 #pragma unroll
     for (int i = 0; i < LA; i++) EI[i] = seed_pair<0>(A[i]);
-    uint32_t fh = 0, rh = 0, cap = 0, bits = 0;
-    uint8_t *hmb = reinterpret_cast<uint8_t *>(S.hm[lane]);
-    hash_steps<L, T, LA, 0>(src, W, A, EI, EO, fh, rh, cap, bits, bound, hmb, S, lane);
+    uint32_t fh = 0, rh = 0, bits = 0;
+    hash_steps<L, T, LA, 0>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
 }
 
 // Same loop for a run-time l (1..64): bytes are fetched one by one from LDS.  Slower; only l values
 // without a static instantiation come here.
-template <class WL>
-__device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 *__restrict__ tab, uint32_t bound, int lane, WL &S,
-                                         uint32_t l, int np) {
+__device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 *__restrict__ tab, uint32_t bound, int lane,
+                                                  uint32_t l, int np, uint32_t (&caps)[NPC], uint32_t (&raw)[5]) {
     const uint8_t *q = D + 16 * np * lane;
     uint32_t fh = 0, rh = 0;
     for (uint32_t i = 0; i < l; i++) {
@@ -268,50 +280,49 @@ __device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 
         fh = __builtin_rotateleft32(fh, 1) ^ ti.x;
         rh = __builtin_rotateright32(rh, 1) ^ ti.y;
     }
-    uint32_t cap = 0, bits = 0;
-    uint8_t *hmb = reinterpret_cast<uint8_t *>(S.hm[lane]);
-    for (int pos = 0; pos < 16 * np; pos++) {
-        uint32_t hv = fh < rh ? fh : rh;
-        bool hit = hv <= bound;
-        cap = hit ? hv : cap;
-        bits = (bits << 1) | (hit ? 1u : 0u);
-        uint2 to = tab_out(tab, q[pos]);
-        uint2 ti = tab_in(tab, q[pos + l]);
-        fh = __builtin_rotateleft32(fh, 1) ^ to.x ^ ti.x;
-        rh = __builtin_rotateright32(rh, 1) ^ to.y ^ ti.y;
-        if ((pos & 7) == 7) {
-            hmb[pos >> 3] = (uint8_t)(__builtin_bitreverse32(bits) >> 24);
-            if ((pos & (CAPP - 1)) == CAPP - 1) S.caps[pos / CAPP][lane] = cap;
-            bits = 0;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int g = 0; g < NPC; g++) { // static piece index: caps[] and raw[] stay in registers
+        if (g < np) {
+            uint32_t cap = 0;
+            for (int i = 0; i < CAPP; i++) {
+                const int pos = CAPP * g + i;
+                uint32_t hv = fh < rh ? fh : rh;
+                bool hit = hv <= bound;
+                cap = hit ? hv : cap;
+                bits = (bits << 1) | (hit ? 1u : 0u);
+                uint2 to = tab_out(tab, q[pos]);
+                uint2 ti = tab_in(tab, q[pos + l]);
+                fh = __builtin_rotateleft32(fh, 1) ^ to.x ^ ti.x;
+                rh = __builtin_rotateright32(rh, 1) ^ to.y ^ ti.y;
+            }
+            caps[g] = cap;
+            if (g % 2 == 0) raw[g / 2] = __builtin_bitreverse32(bits) >> 16;
+            else {
+                raw[g / 2] = __builtin_bitreverse32(bits);
+                bits = 0;
+            }
         }
     }
 }
 
 // Everything below is force-inlined into the kernel so that the LDS operands keep their address space
 // (a generic pointer costs a 64-bit add, a null compare and a select per table lookup).
-template <int L, bool HPC, class WL>
-__device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, uint32_t bound,
-                                           int lane, WL &S, uint32_t l, int np) {
-    if constexpr (L > 0) {
-        if constexpr (!HPC) {
-            hash_loop_static<L, 9, REG_LA>(D, bound, lane, S); // raw tiles always span 9 pieces per lane
-        } else {
-            switch (np) { // wave-uniform: the compacted tile is shorter than the raw one
-            case 1: hash_loop_static<L, 1, HPC_LA>(D, bound, lane, S); break;
-            case 3: hash_loop_static<L, 3, HPC_LA>(D, bound, lane, S); break;
-            case 5: hash_loop_static<L, 5, HPC_LA>(D, bound, lane, S); break;
-            case 7: hash_loop_static<L, 7, HPC_LA>(D, bound, lane, S); break;
-            default: hash_loop_static<L, 9, HPC_LA>(D, bound, lane, S); break;
-            }
-        }
-    } else {
-        hash_loop_dynamic(D, tab, bound, lane, S, l, np);
-    }
+template <int L, bool HPC>
+__device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, uint32_t bound, int lane, uint32_t l, int np,
+                                           uint32_t (&caps)[NPC], uint32_t (&raw)[5]) {
+#pragma unroll
+    for (int g = 0; g < NPC; g++) caps[g] = 0;
+#pragma unroll
+    for (int w = 0; w < 5; w++) raw[w] = 0;
+    if constexpr (L > 0) hash_loop_static<L, HPC ? HPC_LA : REG_LA>(D, bound, lane, np, caps, raw);
+    else hash_loop_dynamic(D, tab, bound, lane, l, np, caps, raw);
 }
 
 // Phase stamps (cycles per phase, kept in registers and flushed once per tile to one of 64 shards) exist only in
 // builds with -DS2K_PROFILE (tools/phases.sh): the 16 accumulators cost 32 VGPRs that production kernels need.
 #ifdef S2K_PROFILE
+#define S2K_WAVES_PER_SIMD 2 /* the 16 phase accumulators cost 32 VGPRs */
 #define S2K_STAMP(i)                                                                     \
     do {                                                                                 \
         if (sem.dbg_skip & 8) {                                                          \
@@ -322,29 +333,35 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
         }                                                                                \
     } while (0)
 #else
+#define S2K_WAVES_PER_SIMD 3
 #define S2K_STAMP(i) do { (void)ph; (void)stamp; } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
 // Hpc pre-stage: in-place run-head compaction of the staged tile.  Returns R_t (run heads owned by
 // the tile) and leaves D[0..R_t) = head bytes, D[R_t..R_t+halo_n) = following heads, S.fm / S.hbase /
-// S.halo_pos for the back-map.  `na` accumulates bytes with bit 7 set.
+// S.halo_pos for the back-map.
+//
+// Run-head flags are kept in NATURAL order: bit i of the lane's 144-bit mask (five words) <-> raw byte i of the
+// lane's chunk.  Read starts are forced run heads (every read starts a new run, src/nthash_hpc.rs:138-150 runs per
+// read); they are OR-ed into the masks, the staged bytes are never modified -- any byte value is fine.
 // ------------------------------------------------------------------------------------------------
 template <class WL>
 __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t *__restrict__ bases,
                                                 const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
                                                 uint64_t t0, uint32_t tile_len, uint32_t r0, uint32_t r1, uint32_t l,
-                                                int lane, uint32_t &na, uint32_t &halo_n_out, uint64_t bpos0,
+                                                int lane, uint32_t &halo_n_out, uint64_t bpos0,
                                                 uint32_t prev_byte0, bool forced0, const Sem &sem, uint64_t *ph,
                                                 uint64_t &stamp) {
-    // 1. mark read starts strictly inside the tile (forced run heads: every read starts a new run,
-    //    src/nthash_hpc.rs:138-150 runs per read).  bpos0 = read_off[r0 + 1 + lane] was fetched ahead.
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    // 1. read starts strictly inside the tile -> forced run heads, OR-ed into S.fm (cleared by the caller before the
+    //    tile was staged).  bpos0 = read_off[r0 + 1 + lane] was fetched ahead.
     {
         uint64_t sp = bpos0;
         for (uint64_t c0 = 0;; c0 += 64) {
             if (sp > t0 && sp < t0 + tile_len) {
-                uint32_t o = (uint32_t)(sp - t0);
-                atomicOr(reinterpret_cast<unsigned int *>(D + (o & ~3u)), 0x80u << (8 * (o & 3u)));
+                const uint32_t rel = (uint32_t)(sp - t0), o = rel / TILE_T, i = rel - o * TILE_T;
+                atomicOr(&S.fm[o][i >> 5], 1u << (i & 31u));
             }
             if ((uint64_t)r0 + 1 + c0 + 64 > (uint64_t)r1) break; // wave-uniform: all starts up to r1 covered
             const uint64_t ri = (uint64_t)r0 + 1 + c0 + 64 + lane;
@@ -361,9 +378,12 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         uint4 v = src[p];
         c[4 * p] = v.x; c[4 * p + 1] = v.y; c[4 * p + 2] = v.z; c[4 * p + 3] = v.w;
     }
+    uint32_t fmk[5];
+#pragma unroll
+    for (int g = 0; g < 5; g++) fmk[g] = S.fm[lane][g]; // forced heads
     uint32_t prevw;
     if (lane == 0) {
-        if (forced0) c[0] |= 0x80u; // the tile starts a read
+        if (forced0) fmk[0] |= 1u; // the tile starts a read
         prevw = prev_byte0 << 24;
     } else {
         prevw = (uint32_t)D[TILE_T * lane - 1] << 24;
@@ -374,21 +394,22 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     const uint32_t la_word = lane < 32 ? *reinterpret_cast<const uint32_t *>(D + TILE_BASES + 4 * lane) : 0u;
     const int vb = (int)tile_len - TILE_T * lane;      // valid bytes in this lane's chunk (may be <=0 or >=144)
     const bool partial = tile_len < (uint32_t)TILE_BASES;
-    // 3. pass 1: SWAR head flags -> transposed group masks + count
-    uint32_t fmk[5] = {0, 0, 0, 0, 0};
+    // 3. pass 1: SWAR "differs from its predecessor" per byte -> four flags per dword -> natural-order masks
 #pragma unroll
     for (int d = 0; d < 36; d++) {
-        uint32_t cur = c[d];
-        uint32_t prv = (cur << 8) | (prevw >> 24);
-        uint32_t x = (cur ^ prv) & 0x7F7F7F7Fu;
-        uint32_t t = ((x + 0x7F7F7F7Fu) | cur) & 0x80808080u; // bit7: differs from predecessor, or marked read start
-        if (partial) {
-            int v = vb - 4 * d;
-            uint32_t keep = v >= 4 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << (8 * v)) - 1u));
-            t &= keep;
+        const uint32_t cur = c[d];
+        const uint32_t prv = __builtin_amdgcn_alignbyte(cur, d == 0 ? prevw : c[d - 1], 3); // predecessor of every byte
+        const uint32_t x = cur ^ prv;
+        const uint32_t y = ((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u) >> 7; // 1 per byte that differs
+        const uint32_t nib = __builtin_amdgcn_udot4(y, 0x08040201u, 0u, false);
+        fmk[d >> 3] |= nib << (4 * (d & 7));
+    }
+    if (partial) { // only the stream's last tile: bytes past the end are no run heads
+#pragma unroll
+        for (int g = 0; g < 5; g++) {
+            const int v = vb - 32 * g;
+            fmk[g] &= v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
         }
-        fmk[d >> 3] |= t >> (7 - (d & 7));
-        prevw = cur;
     }
     uint32_t cnt = __popc(fmk[0]) + __popc(fmk[1]) + __popc(fmk[2]) + __popc(fmk[3]) + __popc(fmk[4]);
     uint32_t incl = wave_incl_scan(cnt, lane);
@@ -410,30 +431,38 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     // all lanes hold their raw chunk in registers now -> the buffer may be overwritten in place
     wave_sync();
     S2K_STAMP(14); // compaction: chunk load + flags + scan
-    // 4. pass 2: every byte is stored at slot (#heads at or before it) - 1; bytes of one run carry the
-    //    same value, so only the slot matters.  Slot -1 of lane 0 lands on the scratch byte D[-1].
+    // 4. pass 2: every byte is stored at slot (#heads at or before it) - 1; bytes of one run carry the same value, so
+    //    only the slot matters and nothing is predicated.  Slot -1 of lane 0 lands on the scratch byte D[-1].
+    //    (Byte stores on purpose: a ds_write_b32 at an address that is not a multiple of 4 is executed one lane per cycle --
+    //    64 cycles per wave instruction against ~4 for ds_write_b8, tools/experiments/lds_rate.hip -- so packing the heads
+    //    of a dword with v_perm_b32 and storing them with one unaligned dword store was 2x slower than this.)
     {
-        typedef __attribute__((address_space(3))) uint8_t lds_u8;
-        // LDS byte address of slot 0 minus one (so that "count of heads at or before" indexes directly)
-        uint32_t gaddr = (uint32_t)(uintptr_t)(lds_u8 *)D + base - 1;
+        uint32_t gaddr = (uint32_t)(uintptr_t)(lds_u8 *)D + base - 1; // LDS byte address of slot -1
         auto pass2 = [&](auto partial_c) {
             constexpr bool PARTIAL = decltype(partial_c)::value;
 #pragma unroll
             for (int d = 0; d < 36; d++) {
-                const int g = d >> 3, dd = d & 7;
+                const int g = d >> 3;
+                const uint32_t hi = c[d] >> 8; // bytes 1 and 3 (the d16_hi store takes bits 16..23)
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
-                    const uint32_t a = gaddr + __popc(fmk[g] & at_or_before(dd, b)); // v_and + v_bcnt(+gaddr)
-                    if (!PARTIAL || 4 * d + b < vb) *reinterpret_cast<lds_u8 *>(a) = (uint8_t)(c[d] >> (8 * b));
+                    const int i = (4 * d + b) & 31;
+                    const uint32_t a = gaddr + __popc(fmk[g] & (i == 31 ? 0xFFFFFFFFu : ((2u << i) - 1u))); // v_and + v_bcnt(+gaddr)
+                    if (!PARTIAL || 4 * d + b < vb) {
+                        if (b == 0) asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(c[d]) : "memory");
+                        if (b == 1) asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(hi) : "memory");
+                        if (b == 2) asm volatile("ds_write_b8_d16_hi %0, %1" ::"v"(a), "v"(c[d]) : "memory");
+                        if (b == 3) asm volatile("ds_write_b8_d16_hi %0, %1" ::"v"(a), "v"(hi) : "memory");
+                    }
                 }
-                if (dd == 7) gaddr += __popc(fmk[g]);
+                if ((d & 7) == 7) gaddr += __popc(fmk[g]);
             }
         };
         // full tiles (all but the last of the stream) take the branch-free instantiation
         if (partial) pass2(std::true_type{});
         else pass2(std::false_type{});
     }
-    S2K_STAMP(15); // compaction: byte stores
+    S2K_STAMP(15); // compaction: stores
     // 5. run heads that follow the tile: up to l of them (hash needs l-1, the end position one more); the HpcSimd
     //    tail rule looks 16 heads further for the end of the read
     const uint32_t hl = sem.tail_quirk ? l + 16 : l;
@@ -454,12 +483,11 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
                 else
                     for (int b = 0; b < nval; b++) wv |= (uint32_t)bases[a + b] << (8 * b);
             }
-            na |= wv & (nval >= 4 ? 0x80808080u : (nval <= 0 ? 0u : (0x80808080u & ((1u << (8 * nval)) - 1u))));
             uint32_t pw = __shfl_up(wv, 1);
             if (lane == 0) pw = pb << 24;
             uint32_t prv = (wv << 8) | (pw >> 24);
-            uint32_t x = (wv ^ prv) & 0x7F7F7F7Fu;
-            uint32_t t = (x + 0x7F7F7F7Fu) & 0x80808080u;
+            uint32_t x = wv ^ prv;
+            uint32_t t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
             t &= nval >= 4 ? 0xFFFFFFFFu : (nval <= 0 ? 0u : ((1u << (8 * nval)) - 1u));
             uint32_t cn = __popc(t);
             uint32_t in2 = wave_incl_scan(cn, lane);
@@ -519,7 +547,7 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
         w1[d] = S.fm[lo1][d];
         w2[d] = S.fm[lo2][d];
     }
-    auto decode = [](const uint32_t (&w)[5], uint32_t n) {
+    auto decode = [](const uint32_t (&w)[5], uint32_t n) { // raw offset (inside the lane's chunk) of the lane's n-th run head
         uint32_t g = 0, word = w[0];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
@@ -530,7 +558,7 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
                 word = w[d + 1];
             }
         }
-        return 32 * g + select_nth_32(untranspose(word), n);
+        return 32 * g + select_nth_32(word, n);
     };
     raw_x = TILE_T * lo1 + decode(w1, n1);
     const uint32_t hx = y - R; // only meaningful when !y_in; validated hits guarantee hx < halo_n
@@ -546,7 +574,8 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                                                 uint64_t t0, uint32_t tile_len, uint32_t nh, uint32_t halo_n,
                                                 uint32_t Tq, uint32_t l, uint32_t r0, uint32_t r1, uint64_t bpos0,
                                                 uint64_t rs0, int lane, const Records &rec, uint64_t *pool_cursor,
-                                                uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem, uint64_t *ph,
+                                                uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem,
+                                                const uint32_t (&caps)[NPC], const uint32_t (&raw)[5], uint64_t *ph,
                                                 uint64_t &stamp) {
     // (1) read starts that matter for this tile -> hash-space boundaries HB; an l-mer x is invalid iff
     //     some boundary has HB - w <= x <= HB - 1  (w = l-1 raw positions for Regular: the l-mer must end
@@ -562,7 +591,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
         for (int d = 0; d < 5; d++) {
             int v = vc - 32 * d;
             uint32_t keep = v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
-            vm[d] = S.hm[lane][d] & keep;
+            vm[d] = raw[d] & keep;
         }
     }
     const uint64_t tile_end = t0 + tile_len;
@@ -582,11 +611,10 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 if constexpr (HPC) {
                     if (bpos < tile_end) { // rank of the forced run head at raw offset bpos - t0
                         const uint32_t rel = (uint32_t)(bpos - t0), o = rel / TILE_T, wi = rel % TILE_T;
-                        const uint32_t g = wi >> 5, pi = wi & 31, d = pi >> 2, bb = pi & 3;
-                        const uint32_t before = (((1u << d) - 1u) * 0x01010101u) | ((0x01010101u << d) & ((1u << (8 * bb)) - 1u));
+                        const uint32_t g = wi >> 5;
                         uint32_t c = S.hbase[o];
                         for (uint32_t gg = 0; gg < g; gg++) c += __popc(S.fm[o][gg]);
-                        c += __popc(S.fm[o][g] & before);
+                        c += __popc(S.fm[o][g] & ((1u << (wi & 31u)) - 1u)); // run heads before the forced one
                         HB = (int32_t)c;
                     } else { // first read start (or stream end) after the tile: count the run heads before it
                         HB = -1; // resolved below by the whole wave
@@ -678,7 +706,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 chunk_prev = ((uint64_t)bcast((uint32_t)(bpos >> 32), 63) << 32) | bcast((uint32_t)bpos, 63);
             }
             if (!many && internal && c0 + lane < 63) { // remembered for the per-hit read lookup
-                S.hb[c0 + lane] = HB;
+                S.hb[c0 + lane] = (int16_t)HB;
                 S.rs[c0 + lane + 1] = bpos;
             }
             nb += (uint32_t)__popcll(__ballot(internal));
@@ -740,17 +768,24 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
         if ((uint32_t)lane < njobs) {
             const uint8_t *q = D + S.jobx[lane];
             uint32_t f = 0, r = 0;
-            if constexpr (L > 0) { // all byte reads first, then all seed reads: two LDS round trips in total
-                uint32_t by[L];
+            if constexpr (L > 0) { // groups of 8 bases: byte reads, then seed reads, then the rotate-xors (bounded register use)
 #pragma unroll
-                for (int i = 0; i < L; i++) by[i] = q[i];
-                uint2 ti[L];
+                for (int i0 = 0; i0 < L; i0 += 8) {
+                    uint32_t by[8];
+                    uint2 ti[8];
 #pragma unroll
-                for (int i = 0; i < L; i++) ti[i] = tab_in(tab, by[i]); // IN pair = {h[c], rotl(rc[c], l-1)}
+                    for (int i = 0; i < 8; i++)
+                        if (i0 + i < L) by[i] = q[i0 + i];
 #pragma unroll
-                for (int i = 0; i < L; i++) {
-                    f ^= rotl32(ti[i].x, L - 1 - i);
-                    r ^= rotr32(ti[i].y, L - 1 - i);
+                    for (int i = 0; i < 8; i++)
+                        if (i0 + i < L) ti[i] = tab_in(tab, by[i]); // IN pair = {h[c], rotl(rc[c], l-1)}
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (i0 + i < L) {
+                            f ^= rotl32(ti[i].x, L - 1 - (i0 + i));
+                            r ^= rotr32(ti[i].y, L - 1 - (i0 + i));
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 for (uint32_t i = 0; i < l; i++) {
@@ -768,15 +803,23 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
     //     No global LOADS in here: a load would make the compiler drain the previous round's stores.
     for (uint32_t b0 = 0; b0 < N; b0 += LISTCAP) {
         wave_sync();
-        {
+        { // every lane lists its own hits and stores the kept hash of those that were the last raw hit of their piece
             uint32_t k = myoff;
 #pragma unroll
             for (int d = 0; d < 5; d++) {
                 uint32_t wv = vm[d];
+                const uint32_t rw = raw[d];
+                const uint32_t cap_lo = caps[2 * d], cap_hi = caps[(2 * d + 1) < NPC ? 2 * d + 1 : NPC - 1]; // static indices: registers
                 while (wv) {
                     const uint32_t bit = __builtin_ctz(wv);
                     wv &= wv - 1;
-                    if (k >= b0 && k < b0 + LISTCAP) S.list[k - b0] = (uint16_t)(Tq * lane + 32 * d + bit);
+                    // raw hits after this one inside the same 16-position piece: the kept hash is not this hit's
+                    const uint32_t later = rw & ((0xFFFFu << (bit & 16)) & ~((2u << bit) - 1u));
+                    const uint32_t hvk = (bit & 16) ? cap_hi : cap_lo;
+                    if (k >= b0 && k < b0 + LISTCAP) {
+                        S.list[k - b0] = (uint16_t)((Tq * lane + 32 * d + bit) | (later ? 0x8000u : 0u));
+                        if (!later && !(sem.dbg_skip & 16)) rec.hash[base + k] = hvk;
+                    }
                     k++;
                 }
             }
@@ -786,23 +829,20 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
         const uint32_t bn = N - b0 < (uint32_t)LISTCAP ? N - b0 : (uint32_t)LISTCAP;
         auto rounds = [&](auto many_c) {
         constexpr bool MANY = decltype(many_c)::value;
-        constexpr int U = 2; // hits per lane per iteration: the LDS round trips of the two overlap
+        constexpr int U = 1; // hits per lane per iteration (2 overlapped LDS round trips in round 1, at the price of ~25 VGPRs)
         for (uint32_t k0 = 0; k0 < bn; k0 += 64 * U) {
-            uint32_t kk[U], x[U], hv[U], rid[U];
+            uint32_t kk[U], x[U], rid[U];
             bool act[U], need_re[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 kk[u] = k0 + 64 * u + lane;
                 act[u] = kk[u] < bn;
-                x[u] = hv[u] = rid[u] = 0;
+                x[u] = rid[u] = 0;
                 need_re[u] = false;
                 if (act[u]) {
-                    x[u] = S.list[kk[u]];
-                    const uint32_t o = __umulhi(x[u], rcpTq), bit = x[u] - o * Tq, piece = bit / CAPP; // o = x / Tq
-                    const uint32_t pbits = reinterpret_cast<const uint16_t *>(S.hm[o])[piece]; // hits of the piece, bit j <-> position j
-                    // the kept hash belongs to the piece's last raw hit; pieces cut by nh may hold a stale one
-                    need_re[u] = (pbits >> ((bit & (CAPP - 1)) + 1)) != 0 || (Tq * o + CAPP * piece + CAPP > nh);
-                    hv[u] = S.caps[piece][o];
+                    const uint32_t e = S.list[kk[u]];
+                    x[u] = e & 0x3FFFu;
+                    need_re[u] = (e & 0x8000u) != 0;
                 }
             }
             // hits that were not the last raw hit of their piece (~7 %) have no kept hash: queue them; one lane
@@ -814,15 +854,18 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 if (sem.dbg_skip & 8) ph[7] += (uint64_t)__popcll(jobs);
 #endif
                 if (sem.dbg_skip & 64) jobs = 0;
-                if (jobs) {
-                    const uint32_t nj = (uint32_t)__popcll(jobs);
-                    if (njobs + nj > 64) flush_jobs(); // wave-uniform
-                    if (need_re[u]) {
-                        const uint32_t q = njobs + (uint32_t)__popcll(jobs & ((1ull << lane) - 1ull));
-                        S.jobx[q] = (uint16_t)x[u];
-                        S.jobslot[q] = b0 + kk[u];
+                while (jobs) { // wave-uniform: queue up to JOBCAP jobs, flush, queue the rest
+                    const uint32_t room = (uint32_t)JOBCAP - njobs;
+                    const uint32_t rank = (uint32_t)__popcll(jobs & ((1ull << lane) - 1ull));
+                    const bool mine = need_re[u] && ((jobs >> lane) & 1ull) && rank < room;
+                    if (mine) {
+                        S.jobx[njobs + rank] = (uint16_t)x[u];
+                        S.jobslot[njobs + rank] = b0 + kk[u];
                     }
-                    njobs += nj;
+                    const uint64_t done = __ballot(mine);
+                    njobs += (uint32_t)__popcll(done);
+                    jobs &= ~done;
+                    if (jobs) flush_jobs();
                 }
             }
             S2K_STAMP(8); // round: list read, kept hash, job queueing
@@ -869,7 +912,6 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                     if (!(sem.dbg_skip & 16)) {
                         rec.j[slot] = (uint32_t)(p[u] - rstart);
                         rec.jend[slot] = (uint32_t)(e1[u] - rstart);
-                        if (!need_re[u]) rec.hash[slot] = hv[u];
                         rec.rid[slot] = rid[u];
                     }
                 }
@@ -905,7 +947,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
 // read-table entries of the current tile are fetched before they are needed, so no global-load latency
 // sits on the critical path except in the first iteration.
 template <int L, bool HPC>
-__global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
+__global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
     uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
     uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts) {
@@ -913,11 +955,10 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
     using WL = WaveLdsT<HPC>;
     uint2 *tab = reinterpret_cast<uint2 *>(smem);
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap(); // lut() assumes it
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: everything per tile is scalar
     const uint32_t l = L > 0 ? (uint32_t)L : sem.l;
     for (int c = threadIdx.x; c < 256; c += 64 * TW) {
-        // Hpc tiles carry read-start marks in bit 7 (input is 7-bit there), so the table ignores it
-        uint32_t cc = HPC ? (c & 0x7F) : c;
+        uint32_t cc = c;
         // Simd result semantics map bytes by their low nibble (src/nthash_avx512_32.rs:178-193)
         uint32_t h = sem.simd_seeds ? seed_h_simd(cc) : seed_h_scalar(cc), r = sem.simd_seeds ? seed_rc_simd(cc) : seed_rc_scalar(cc);
         tab[c] = make_uint2(h, rotl32(r, l - 1));
@@ -975,13 +1016,11 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
         const uint64_t rem = n_bases - t0;
         const uint32_t avail = rem > (uint64_t)(TILE_BASES + 128) ? (uint32_t)(TILE_BASES + 128) : (uint32_t)rem;
         const uint32_t tile_len = rem > (uint64_t)TILE_BASES ? (uint32_t)TILE_BASES : (uint32_t)rem;
-        uint32_t na = 0;
         // ---- stage the tile (+128 B look-ahead) in LDS: 1 KiB per wave-instruction ----------------------
         if (have_pre) {
 #pragma unroll
             for (int r = 0; r < NPRE; r++) {
                 const uint32_t off = 16 * lane + 1024 * r;
-                if (r < NPRE - 1) na |= (pre[r].x | pre[r].y | pre[r].z | pre[r].w);
                 if (r < NPRE - 1 || lane < 8) *reinterpret_cast<uint4 *>(D + off) = pre[r];
             }
         } else { // tile at the end of the stream: guarded loads, zero past the end
@@ -997,15 +1036,16 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
                     for (uint32_t b = 0; off + b < avail && b < 16; b++) tmp[b >> 2] |= (uint32_t)g[off + b] << (8 * (b & 3));
                     v = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
                 }
-                if (r < NPRE - 1) na |= (v.x | v.y | v.z | v.w);
                 *reinterpret_cast<uint4 *>(D + off) = v;
             }
             prevb = t0 > 0 ? (uint32_t)bases[t0 - 1] : 0u;
         }
         const uint32_t cr0 = r0, cr1 = r1, cprev = prevb; // this tile's values (the registers get reused below)
         if (lane == 0) S.buf[HS_OFF - 1] = 0;
+        if constexpr (HPC) {
 #pragma unroll
-        for (int g2 = 0; g2 < 5; g2++) S.hm[lane][g2] = 0;
+            for (int g2 = 0; g2 < 5; g2++) S.fm[lane][g2] = 0; // read-start marks are OR-ed in by hpc_compact
+        }
         wave_sync();
         S2K_STAMP(0); // staging
 
@@ -1013,19 +1053,16 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
         uint32_t halo_n = 0;
         int np = 9;
         if constexpr (HPC) {
+#ifndef EXP_NOCOMPACT
             if (!(sem.dbg_skip & 4))
-                nh = hpc_compact(D, S, bases, read_off, n_reads, n_bases, t0, tile_len, cr0, cr1, l, lane, na, halo_n, bpos0,
+                nh = hpc_compact(D, S, bases, read_off, n_reads, n_bases, t0, tile_len, cr0, cr1, l, lane, halo_n, bpos0,
                                  cprev, t0 == 0 || rs0 == t0, sem, ph, stamp);
-            if (__any((na & 0x80808080u) != 0)) { // bytes >= 0x80: the exact path is the serial kernel
-                if (lane == 0) counts->non_ascii = 1;
-            }
+#endif
             int need = (int)((nh + 1023) >> 10);
             np = need <= 1 ? 1 : need <= 3 ? 3 : need <= 5 ? 5 : need <= 7 ? 7 : 9;
         }
         S2K_STAMP(1); // hpc compaction
-        // ---- next tile's loads: issued before the hash loop (Regular: their latency hides under it) or right
-        //      after it (Hpc: 40 staging registers live across the hash loop spill there; the dense phase covers
-        //      most of the latency instead) -----------------------------------------------------------------------
+        // ---- next tile's loads: issued right after the hash loop; the dense phase covers their latency ----------
         uint64_t bposn = ~0ull, rs0n = 0;
         uint32_t r0nn = 0, r1nn = 0;
         auto issue_next = [&]() {
@@ -1041,22 +1078,36 @@ __global__ __launch_bounds__(64 * TW, 2) void tile_minimizer_kernel(
                     r1nn = tile_read0[t + 2 * n_waves + 1];
                 }
             }
+            if (!have_pre) { // tell the compiler the staged registers are dead (they would stay live across the whole loop body)
+#pragma unroll
+                for (int r = 0; r < NPRE; r++) pre[r] = make_uint4(0, 0, 0, 0);
+                prevb = 0;
+            }
         };
-        if constexpr (!HPC) issue_next();
         const uint32_t Tq = 16 * np;
         uint32_t N = 0;
         uint64_t base = 0;
+        uint32_t caps[NPC], raw[5]; // kept hashes / hit bits of this lane's 144 hash positions (hash_stage)
+#pragma unroll
+        for (int g2 = 0; g2 < NPC; g2++) caps[g2] = 0;
+#pragma unroll
+        for (int g2 = 0; g2 < 5; g2++) raw[g2] = 0;
         if (nh != 0 && sem.enabled) {
             // ---- the hot loop ------------------------------------------------------------------------------
-            if (!(sem.dbg_skip & 1)) hash_stage<L, HPC>(D, tab, sem.bound_le, lane, S, l, np);
+#ifndef EXP_NOHASH
+            if (!(sem.dbg_skip & 1)) hash_stage<L, HPC>(D, tab, sem.bound_le, lane, l, np, caps, raw);
+#endif
             wave_sync();
+            __builtin_amdgcn_sched_barrier(0);
             S2K_STAMP(2); // hash loop
         }
-        if constexpr (HPC) issue_next();
+        issue_next(); // after the hash loop: 40 staging registers live across it would not fit three waves per SIMD
         if (nh != 0 && sem.enabled) {
+#ifndef EXP_NODENSE
             if (!(sem.dbg_skip & 2))
                 N = dense_phase<L, HPC>(S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
-                                     rs0, lane, rec, pool_cursor, mn_cnt, counts, base, sem, ph, stamp);
+                                     rs0, lane, rec, pool_cursor, mn_cnt, counts, base, sem, caps, raw, ph, stamp);
+#endif
             S2K_STAMP(5); // rounds
         }
         if (lane == 0) {

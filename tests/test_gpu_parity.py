@@ -146,15 +146,16 @@ def test_odd_bytes(eng, oracle):
     base = rand_read(rng, 30000, hp=0.2, odd=0.05)
     compare(eng, oracle, [base, base.lower(), base[:100]], 31, 5, 0.05, HM.Regular, expect_path=0, tag="odd")
     compare(eng, oracle, [base, base.lower(), base[:100]], 31, 5, 0.05, HM.Hpc, expect_path=0, tag="odd")
-    # bytes >= 0x80: Regular tiles take them (seed 1); Hpc tiles use bit 7 as the read-start mark and
-    # hand the call to the exact serial kernels
+    # bytes >= 0x80 are ordinary "other" bytes (seed 1) in both modes: the tiled kernels take them (round 1 handed an
+    # Hpc call with such a byte to the serial kernels)
     hi = bytearray(base)
     for i in range(0, len(hi), 997):
         hi[i] = 0x80 | (hi[i] & 0x7F)
     hi[5000:5040] = bytes([0xC1]) * 40
     reads = [bytes(hi), rand_read(rng, 12000)]
     compare(eng, oracle, reads, 31, 5, 0.05, HM.Regular, expect_path=0, tag="hibit")
-    compare(eng, oracle, reads, 31, 5, 0.05, HM.Hpc, expect_path=1, tag="hibit")
+    compare(eng, oracle, reads, 31, 5, 0.05, HM.Hpc, expect_path=0, tag="hibit")
+    compare(eng, oracle, reads, 31, 5, 0.05, HM.HpcSimd, expect_path=0, tag="hibit")
 
 
 def test_simd_result_semantics(eng, oracle):
