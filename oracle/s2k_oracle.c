@@ -7,6 +7,7 @@
  * Plain C11, no dependencies beyond libc + pthreads.  Written from the reference's
  * *behaviour*; every function cites the file:line (under /root/reference) it restates.
  */
+#define _GNU_SOURCE /* pthread_barrier_t, clock_gettime under -std=c11 */
 #include "s2k_oracle.h"
 
 #include <math.h>
@@ -749,6 +750,72 @@ uint64_t s2k_oracle_batch(const uint8_t *bases, const uint64_t *off, uint64_t n_
     }
     free(cnt);
     return total;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Timed count-only pass for bench.py's cpu_baseline: the worker threads are created first, each touches its shard once
+ * (warm-up, untimed), all meet at a barrier, then every thread iterates `repeats` times over its shard; the clock runs
+ * from the barrier to the last join.  (Timing thread creation and a 10 ms pass, as round 1 did, under-reported the
+ * all-core rate several times.)  Returns the k-min-mer total of ONE pass; *seconds = wall time of the timed passes.
+ * ---------------------------------------------------------------------------------------- */
+#include <time.h>
+struct timed_job {
+    struct batch_job jb;
+    int repeats;
+    pthread_barrier_t *bar;
+};
+static void *timed_worker(void *p) {
+    struct timed_job *tj = (struct timed_job *)p;
+    struct batch_job warm = tj->jb;
+    if (warm.r1 > warm.r0 + 8) warm.r1 = warm.r0 + 8; /* a few reads: page in the code, the tables and the thread */
+    batch_count_worker(&warm);
+    pthread_barrier_wait(tj->bar);
+    uint64_t tot = 0;
+    for (int i = 0; i < tj->repeats; i++) {
+        batch_count_worker(&tj->jb);
+        tot = tj->jb.total;
+    }
+    tj->jb.total = tot;
+    return NULL;
+}
+uint64_t s2k_oracle_batch_count_timed(const uint8_t *bases, const uint64_t *off, uint64_t n_reads, unsigned l, unsigned k,
+                                      double density, int mode, int threads, int repeats, double *seconds) {
+    tables();
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > n_reads) threads = n_reads ? (int)n_reads : 1;
+    if (repeats < 1) repeats = 1;
+    struct timed_job *jobs = (struct timed_job *)calloc((size_t)threads, sizeof(*jobs));
+    pthread_t *th = (pthread_t *)malloc(sizeof(*th) * (size_t)threads);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)threads + 1);
+    uint64_t total_bases = n_reads ? off[n_reads] - off[0] : 0, r = 0;
+    for (int t = 0; t < threads; t++) { /* contiguous shards balanced by cumulative bases */
+        struct batch_job *jb = &jobs[t].jb;
+        jb->bases = bases; jb->off = off; jb->l = l; jb->k = k; jb->bound = s2k_oracle_hash_bound(density); jb->mode = mode;
+        jb->r0 = r;
+        uint64_t target = off[0] + (total_bases * (uint64_t)(t + 1)) / (uint64_t)threads;
+        if (t == threads - 1) r = n_reads;
+        else
+            while (r < n_reads && off[r + 1] <= target) r++;
+        jb->r1 = r;
+        jobs[t].repeats = repeats;
+        jobs[t].bar = &bar;
+        pthread_create(&th[t], NULL, timed_worker, &jobs[t]);
+    }
+    struct timespec a, b;
+    pthread_barrier_wait(&bar);
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    uint64_t tot = 0;
+    for (int t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        tot += jobs[t].jb.total;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    if (seconds) *seconds = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+    pthread_barrier_destroy(&bar);
+    free(jobs);
+    free(th);
+    return k ? tot : 0;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -199,6 +199,18 @@ class Oracle:
         return int(self.lib.s2k_oracle_batch(_ptr(bases, _u8p), _ptr(off, _u64p), len(off) - 1, l, k, density, mode,
                                              threads, None, None, None, None, None, 0))
 
+    def batch_count_clocked(self, bases, off, l, k, density, mode, threads=1, repeats=1):
+        """count-only passes timed inside the library (threads created and warmed before the clock starts);
+        returns (k-min-mers of one pass, seconds for `repeats` passes)."""
+        bases = self._seq(bases)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        sec = C.c_double(0.0)
+        fn = self.lib.s2k_oracle_batch_count_timed
+        fn.restype = C.c_uint64
+        fn.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        n = fn(_ptr(bases, _u8p), _ptr(off, _u64p), len(off) - 1, l, k, density, mode, int(threads), int(repeats), C.byref(sec))
+        return int(n), float(sec.value)
+
     def synth_checksums(self, seed, n_reads, read_len, l, k, density, mode, threads=1):
         """whole-run checksums of a synthetic batch generated read by read (no big host buffer)"""
         out = np.zeros(6, dtype=np.uint64)
@@ -291,6 +303,17 @@ class OracleAvx512:
         off = np.ascontiguousarray(off, dtype=np.uint64)
         return int(self.lib.s2k_avx512_batch_count_mt(_ptr(bases, _u8p), _ptr(off, _u64p), len(off) - 1, l, k, density, int(hpc),
                                                       int(threads)))
+
+
+    def batch_count_clocked(self, bases, off, l, k, density, hpc, threads=1, repeats=1):
+        bases = Oracle._seq(bases)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        sec = C.c_double(0.0)
+        fn = self.lib.s2k_avx512_batch_count_timed
+        fn.restype = C.c_uint64
+        fn.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        n = fn(_ptr(bases, _u8p), _ptr(off, _u64p), len(off) - 1, l, k, density, int(hpc), int(threads), int(repeats), C.byref(sec))
+        return int(n), float(sec.value)
 
 
 _default = None

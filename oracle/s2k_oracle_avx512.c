@@ -14,6 +14,7 @@
  * Build: gcc -O3 -mavx512f -mavx512bw -mavx512vl -mavx512vbmi2 (the loader adds the flags; the entry points
  * report "unsupported" at run time when the CPU lacks them).
  */
+#define _GNU_SOURCE /* pthread_barrier_t, clock_gettime under -std=c11 */
 #include <immintrin.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -263,6 +264,54 @@ uint64_t s2k_avx512_batch_count_mt(const uint8_t *bases, const uint64_t *off, ui
         pthread_join(th[t], NULL);
         tot += jobs[t].total;
     }
+    free(jobs);
+    free(th);
+    return tot;
+}
+
+/* Timed variant for bench.py (see s2k_oracle_batch_count_timed): threads first, warm-up, barrier, `repeats` passes. */
+#include <time.h>
+struct avx_tjob {
+    struct avx_job j;
+    int repeats;
+    pthread_barrier_t *bar;
+};
+static void *avx_timed_worker(void *p) {
+    struct avx_tjob *t = (struct avx_tjob *)p;
+    uint64_t w1 = t->j.r0 + 8 < t->j.r1 ? t->j.r0 + 8 : t->j.r1;
+    (void)s2k_avx512_batch_count(t->j.bases, t->j.off, t->j.r0, w1, t->j.l, t->j.k, t->j.density, t->j.hpc);
+    pthread_barrier_wait(t->bar);
+    for (int i = 0; i < t->repeats; i++)
+        t->j.total = s2k_avx512_batch_count(t->j.bases, t->j.off, t->j.r0, t->j.r1, t->j.l, t->j.k, t->j.density, t->j.hpc);
+    return NULL;
+}
+uint64_t s2k_avx512_batch_count_timed(const uint8_t *bases, const uint64_t *off, uint64_t n_reads, unsigned l, unsigned k,
+                                      double density, int hpc, int threads, int repeats, double *seconds) {
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > n_reads) threads = n_reads ? (int)n_reads : 1;
+    if (repeats < 1) repeats = 1;
+    struct avx_tjob *jobs = (struct avx_tjob *)calloc((size_t)threads, sizeof(*jobs));
+    pthread_t *th = (pthread_t *)malloc(sizeof(*th) * (size_t)threads);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)threads + 1);
+    for (int t = 0; t < threads; t++) {
+        jobs[t].j = (struct avx_job){bases, off, n_reads * (uint64_t)t / (uint64_t)threads, n_reads * (uint64_t)(t + 1) / (uint64_t)threads,
+                                     l, k, density, hpc, 0};
+        jobs[t].repeats = repeats;
+        jobs[t].bar = &bar;
+        pthread_create(&th[t], NULL, avx_timed_worker, &jobs[t]);
+    }
+    struct timespec a, b;
+    pthread_barrier_wait(&bar);
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    uint64_t tot = 0;
+    for (int t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        tot += jobs[t].j.total;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    if (seconds) *seconds = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+    pthread_barrier_destroy(&bar);
     free(jobs);
     free(th);
     return tot;

@@ -829,7 +829,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
         const uint32_t bn = N - b0 < (uint32_t)LISTCAP ? N - b0 : (uint32_t)LISTCAP;
         auto rounds = [&](auto many_c) {
         constexpr bool MANY = decltype(many_c)::value;
-        constexpr int U = 1; // hits per lane per iteration (2 overlapped LDS round trips in round 1, at the price of ~25 VGPRs)
+        constexpr int U = HPC ? 2 : 1; // hits per lane per iteration: Hpc (two waves per SIMD, 256 VGPRs) overlaps the LDS round trips of two back-maps
         for (uint32_t k0 = 0; k0 < bn; k0 += 64 * U) {
             uint32_t kk[U], x[U], rid[U];
             bool act[U], need_re[U];
@@ -947,7 +947,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
 // read-table entries of the current tile are fetched before they are needed, so no global-load latency
 // sits on the critical path except in the first iteration.
 template <int L, bool HPC>
-__global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_kernel(
+__global__ __launch_bounds__(64 * TW, HPC ? 2 : S2K_WAVES_PER_SIMD) void tile_minimizer_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
     uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
     uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts) {
