@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- input bases/s (Gbp/s) of k-min-mer extraction, l=31 k=10 d=0.01, on MI355X.
 
-Workload (BASELINE.json configs[1]): per GPU, 1 000 000 synthetic uniform-random ACGT
-reads of 10 kbp (10 Gbp of ASCII, generated in HBM by the library's splitmix64 generator -- the
-reference's benches/bench.rs:19-31 convention).  A "step" is one pass of the whole hot path
-(s2k_extract_device: minimizer kernel + scans + k-min-mer kernel) over that resident batch.  Reads
-shard across GPUs with no data-path collective (weak scaling: every rank owns its own 10 Gbp); the
-only cross-GPU traffic is an all-reduce of the count vector.
+Workloads (BASELINE.json configs):
+  c2  (default, configs[1])  per GPU 1 000 000 synthetic uniform-random ACGT reads of 10 kbp (10 Gbp of ASCII), the
+      reference's benches/bench.rs:19-31 convention.  Weak scaling: every rank owns its own 10 Gbp.
+  ont (configs[2])           ONE batch of ragged reads -- lengths lognormal(mean 20 kbp, sigma 0.5) clipped to
+      [1 k, 200 k], 1.25 M reads (~25 Gbp) per GPU, i.e. 10 M reads / ~200 Gbp on 8 GPUs -- cut into contiguous
+      shards balanced by cumulative bases (sharding.shard_bounds); rank r runs the HIP path on its shard.
+      value = all bases / slowest shard's time, so the load balance over ragged lengths is part of the number.
+Bases are generated in HBM by the library's splitmix64 generator (rank r generates exactly its part of the one
+global stream).  A "step" is one pass of the whole hot path (s2k_extract_device: tile index + minimizer kernel + scans +
+k-min-mer kernel) over the resident batch.  Reads shard across GPUs with no data-path collective; the only cross-GPU
+traffic is an all-reduce of the count vector (RCCL).
+
+Launch: `python bench.py --gpus N` starts N rank processes itself (fresh children, before anything touches the GPU);
+under torchrun / torch.distributed.run (WORLD_SIZE set) it is one rank and --gpus must equal WORLD_SIZE.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- algorithmic bytes of the dominant kernel / its HIP-event duration, vs HBM peak
-  cpu_baseline -- the CPU oracle (a port of the reference's scalar path) timed on this host
+  roofline     -- algorithmic bytes / HIP-event time of ALL kernels of a step, vs HBM peak; the dominant kernel's own
+                  figure is kept beside it (kernel_*)
+  cpu_baseline -- the CPU oracle (a port of the reference's scalar path) timed on this host, N=1 only
 """
 import argparse
-import ctypes as C
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,32 +36,110 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
-    ap.add_argument("--read-len", type=int, default=10_000)
+    ap.add_argument("--workload", choices=["c2", "ont"], default="c2")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default 1 000 000 for c2, 1 250 000 for ont)")
+    ap.add_argument("--read-len", type=int, default=10_000, help="c2: read length")
     ap.add_argument("--l", type=int, default=31)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--density", type=float, default=0.01)
     ap.add_argument("--mode", choices=["hpc", "regular"], default="hpc",
                     help="headline HashMode: hpc = the full fused path (HPC + ntHash + select + emit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=120_000, help="reads of the same workload timed on the CPU (1 thread)")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the run of the other scalar HashMode")
+    ap.add_argument("--cpu-sample-reads", type=int, default=120_000, help="reads of the same workload timed on the CPU")
     ap.add_argument("--verify-reads", type=int, default=300)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: map every rank to GPU 0")
-    args = ap.parse_args()
+    ap.add_argument("--dump-shard", default=None, help="(tests) write this rank's outputs to <path>.rank<r>.npz")
+    return ap.parse_args()
 
+
+def spawn_ranks(n):
+    """Start n rank processes (fresh interpreters; this parent never touches the GPU) and wait for them."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask and the cgroup CPU quota both bound it (a GPU box hands a
+    1-GPU job a share of the host, e.g. 16 of 256 hardware threads: timing 256 threads there measures the quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            q, per = parse(open(path).read())
+            if q != "max" and int(q) > 0:
+                n = min(n, max(1, int(math.ceil(int(q) / int(per)))))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
+def ont_lengths(n_reads, seed=2):
+    """lognormal with mean 20 kbp, sigma 0.5, clipped to [1 k, 200 k]; identical on every rank."""
+    import numpy as np
+
+    sigma = 0.5
+    mu = math.log(20000.0) - sigma * sigma / 2.0
+    x = np.random.default_rng(seed).lognormal(mu, sigma, size=n_reads)
+    return np.clip(x, 1000, 200000).astype(np.int64)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let bench.py spawn them)" % (args.gpus, world))
+
+    import numpy as np
     import torch
     from s2k_loader import import_package
 
     pkg = import_package()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -66,20 +153,47 @@ def main():
         else:
             dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the few collective words live
     torch.cuda.set_device(dev)
     eng = pkg.Engine(local_rank)
     stream = torch.cuda.current_stream(dev)
     eng.set_stream(stream.cuda_stream)  # one stream for torch events and the library's kernels
 
-    n_reads, rl = args.reads, args.read_len
-    n_bases = n_reads * rl
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("s2k_sharding", os.path.join(ROOT, "rust-seq2kminmers_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+
     mode = pkg.HashMode.Hpc if args.mode == "hpc" else pkg.HashMode.Regular
     other = pkg.HashMode.Regular if args.mode == "hpc" else pkg.HashMode.Hpc
 
-    # ---- inputs resident in HBM before the timed region -----------------------------------------
+    # ---- this rank's shard, resident in HBM before the timed region ---------------------------------
+    if args.workload == "c2":
+        n_reads, rl = args.reads or 1_000_000, args.read_len
+        n_bases = n_reads * rl
+        first_base = rank * n_bases  # each rank owns a distinct part of the stream
+        seed = 1
+        d_off = torch.arange(0, n_reads + 1, dtype=torch.int64, device=dev) * rl
+        host_off = None
+        shard_info = {"reads_per_gpu": n_reads, "read_len": rl, "sharding": "reads, contiguous per rank"}
+        wl_text = "%d x %d bp uniform-random ACGT reads per GPU (%.1f Gbp/GPU)" % (n_reads, rl, n_bases / 1e9)
+    else:
+        per_gpu = args.reads or 1_250_000
+        lens = ont_lengths(per_gpu * world)
+        goff = np.zeros(len(lens) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=goff[1:])
+        b = sharding.shard_bounds(goff, world)
+        r0, r1 = int(b[rank]), int(b[rank + 1])
+        host_off = (goff[r0: r1 + 1] - goff[r0]).astype(np.uint64)
+        n_reads, n_bases, first_base, seed = r1 - r0, int(host_off[-1]), int(goff[r0]), 2
+        d_off = torch.from_numpy(host_off.astype(np.int64)).to(dev)
+        shard_info = {"reads_total": int(len(lens)), "bases_total": int(goff[-1]), "reads_this_rank": n_reads, "bases_this_rank": n_bases,
+                      "sharding": "contiguous read ranges balanced by cumulative bases (sharding.shard_bounds)"}
+        wl_text = "%d ragged reads, lognormal(mean 20 kbp, sigma 0.5) clipped [1k,200k] (%.1f Gbp) in %d shard(s)" % (
+            len(lens), int(goff[-1]) / 1e9, world)
     d_bases = torch.empty(n_bases + 256, dtype=torch.uint8, device=dev)
-    d_off = torch.arange(0, n_reads + 1, dtype=torch.int64, device=dev) * rl
-    eng.synth_bases_device(1, rank * n_bases, n_bases, d_bases.data_ptr())  # each rank owns a distinct shard
+    eng.synth_bases_device(seed, first_base, n_bases, d_bases.data_ptr())
     cap = int(n_bases * (2.4 * args.density)) + 1_000_000
     outs = {"km_off": torch.empty(n_reads + 1, dtype=torch.int64, device=dev), "hash": torch.empty(cap, dtype=torch.int64, device=dev),
             "start": torch.empty(cap, dtype=torch.int32, device=dev), "end": torch.empty(cap, dtype=torch.int32, device=dev),
@@ -101,7 +215,7 @@ def main():
         for _ in range(warmup):
             step(m)
         eng.sync()
-        eng.enable_timing(True)  # HIP events around the kernels, on the same stream
+        eng.enable_timing(True)  # HIP events around the kernels, on the stream the kernels are launched on
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -113,11 +227,12 @@ def main():
         km_ms, _ = eng.timing_total(2)
         all_ms, _ = eng.timing_total(0)
         eng.enable_timing(False)
+        assert k_n == steps, "internal re-runs (workspace growth) inside the timed region: %d event sets for %d steps" % (k_n, steps)
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, counts, k_ms / max(k_n, 1), km_ms / max(k_n, 1), all_ms / max(k_n, 1)
+        return dt, counts, k_ms / steps, km_ms / steps, all_ms / steps
 
     dt, counts, min_ms, km_ms, pipe_ms = timed(mode, args.steps, args.warmup)
     assert counts["path"] == 0, "the tiled HIP kernels must be the ones measured"
@@ -128,10 +243,10 @@ def main():
 
         orc = so.get()
         nv = min(args.verify_reads, n_reads)
-        hb = d_bases[: nv * rl].cpu().numpy()
-        assert (hb[: 4096] == orc.synth_bases(1, 0, 4096)).all()
-        ref = orc.batch(hb, np.arange(nv + 1, dtype=np.uint64) * rl, args.l, args.k, args.density,
-                        so.HPC if mode == pkg.HashMode.Hpc else so.REGULAR, threads=4)
+        voff = np.arange(nv + 1, dtype=np.uint64) * args.read_len if host_off is None else host_off[: nv + 1]
+        hb = d_bases[: int(voff[-1])].cpu().numpy()
+        assert (hb[: 4096] == orc.synth_bases(seed, first_base, min(4096, len(hb)))[: len(hb)]).all()
+        ref = orc.batch(hb, voff, args.l, args.k, args.density, so.HPC if mode == pkg.HashMode.Hpc else so.REGULAR, threads=4)
         nk = ref["n"]
         verified = bool((outs["km_off"][: nv + 1].cpu().numpy().view(np.uint64) == ref["km_off"]).all()
                         and (outs["hash"][:nk].cpu().numpy().view(np.uint64) == ref["hash"]).all()
@@ -139,54 +254,79 @@ def main():
                         and (outs["end"][:nk].cpu().numpy().view(np.uint32) == ref["end"]).all()
                         and (outs["rev"][:nk].cpu().numpy() == ref["rev"]).all())
         assert verified, "GPU output differs from the oracle on the verification sample"
+    if args.dump_shard:  # tests: concatenating the ranks' dumps must reproduce the unsharded run
+        nk = counts["n_kminmers"]
+        np.savez(args.dump_shard + ".rank%d.npz" % rank, km_off=outs["km_off"].cpu().numpy().view(np.uint64),
+                 hash=outs["hash"][:nk].cpu().numpy().view(np.uint64), start=outs["start"][:nk].cpu().numpy().view(np.uint32),
+                 end=outs["end"][:nk].cpu().numpy().view(np.uint32), rev=outs["rev"][:nk].cpu().numpy(), first_base=first_base, n_bases=n_bases)
     # the other scalar HashMode, for the record (not the headline)
-    dt2, counts2, min_ms2, km_ms2, pipe_ms2 = timed(other, max(2, args.steps // 2), 1)
+    other_line = None
+    if not args.no_other_mode:
+        s2 = max(2, args.steps // 2)
+        dt2, counts2, min_ms2, km_ms2, pipe_ms2 = timed(other, s2, 1)
+        alg2 = counts2["n_bases"] + 17 * counts2["n_kminmers"] + 16 * (n_reads + 1)
+        tot2 = sharding.allreduce_counts(counts2, dist, red_dev)
+        other_line = {"mode": "regular" if args.mode == "hpc" else "hpc", "value": round(tot2["n_bases"] * s2 / dt2 / 1e9, 2), "unit": "Gbp/s",
+                      "kernel_ms": round(min_ms2, 3), "kminmer_kernel_ms": round(km_ms2, 3), "pipeline_ms": round(pipe_ms2, 3),
+                      "roofline_frac": round(alg2 / (pipe_ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     # whole-job counts: the only collective on this path (RCCL all-reduce of a few words)
-    import importlib.util
-
-    spec = importlib.util.spec_from_file_location("s2k_sharding", os.path.join(ROOT, "rust-seq2kminmers_amd", "sharding.py"))
-    sharding = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(sharding)
-    tot = sharding.allreduce_counts(counts, dist, dev)
+    tot = sharding.allreduce_counts(counts, dist, red_dev)
     tot_bases, tot_min, tot_km = tot["n_bases"], tot["n_minimizers"], tot["n_kminmers"]
+    balance = None
+    if dist is not None:
+        t = torch.tensor([float(n_bases)], dtype=torch.float64, device=red_dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        balance = round(float(tmax.item()) / (tot_bases / world), 4)  # largest shard / mean shard, in bases
 
-    # ---- roofline of the dominant kernel (tiled minimizer kernel), per launch ---------------------
-    # B = N_bases*1 + N_kminmers*17 + 16*(N_reads+1)   (each input byte once, each k-min-mer once)
+    # ---- roofline (rank 0's launch): SURVEY.md 8d  B = N_bases*1 + N_kminmers*17 + 16*(N_reads+1) --------------------
+    # each input byte once, each k-min-mer once (u64 hash + u32 start + u32 end + u8 rev), both offset tables;
+    # divided by the HIP-event time of ALL kernels of the step (tile index, minimizer kernel, scans, k-min-mer kernel).
     alg_bytes = counts["n_bases"] + 17 * counts["n_kminmers"] + 16 * (n_reads + 1)
-    achieved = alg_bytes / (min_ms * 1e-3) / 1e9
-    traffic = None
+    achieved = alg_bytes / (pipe_ms * 1e-3) / 1e9
+    # the dominant kernel on its own: it reads the bases and the read table once and writes 16 B per minimizer record
+    kern_bytes = counts["n_bases"] + 16 * counts["n_minimizers"] + 8 * (n_reads + 1)
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and args.workload == "c2":
         try:
             tj = json.load(open(tpath))
             if tj.get("mode") == args.mode and tj.get("n_bases") == n_bases:
-                traffic = tj.get("hbm_bytes_per_launch")
+                traffic, traffic_src = tj.get("hbm_bytes_per_step"), tj.get("source")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "tile_minimizer_kernel<31,%s>" % ("hpc" if mode == pkg.HashMode.Hpc else "regular"),
-                "kernel_ms": round(min_ms, 3), "kminmer_kernel_ms": round(km_ms, 3), "pipeline_ms": round(pipe_ms, 3),
-                "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_base": round(alg_bytes / n_bases, 4)}
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_step": int(alg_bytes), "bytes_per_base": round(alg_bytes / max(n_bases, 1), 4),
+                "time_ms": round(pipe_ms, 3), "time": "HIP events around all kernels of a step (s2k_timing_total(0)), averaged over the timed steps",
+                "kernel": "tile_minimizer_kernel<%d,%s>" % (args.l, "hpc" if mode == pkg.HashMode.Hpc else "regular"),
+                "kernel_ms": round(min_ms, 3), "kernel_bytes": int(kern_bytes),
+                "kernel_frac": round(kern_bytes / (min_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kminmer_kernel_ms": round(km_ms, 3),
+                "limiter": "integer VALU issue, not HBM: see DESIGN.md 3.1 and tools/experiments/valu_rate.hip"}
 
     # ---- CPU baseline: the oracle = scalar port of the reference, on this host's cores --------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only (the host cores are shared by all ranks)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "c2":  # N=1 only (the host cores are shared by all ranks)
         from oracle import s2k_oracle as so
 
         orc = so.Oracle(native=True)  # -O3 -march=native, like the reference's -Ctarget-cpu=native (.cargo/config:2)
         ns = min(args.cpu_sample_reads, n_reads)
+        rl = args.read_len
         hb = d_bases[: ns * rl].cpu().numpy()
         hoff = np.arange(ns + 1, dtype=np.uint64) * rl
         omode = so.HPC if mode == pkg.HashMode.Hpc else so.REGULAR
-        t0 = time.perf_counter()
-        n1 = orc.batch_count_timed(hb, hoff, args.l, args.k, args.density, omode, threads=1)
-        t1 = time.perf_counter() - t0
-        ncpu = os.cpu_count() or 1
-        t0 = time.perf_counter()
-        n2 = orc.batch_count_timed(hb, hoff, args.l, args.k, args.density, omode, threads=ncpu)
-        t2 = time.perf_counter() - t0
+        ncpu, nphys, nhw = usable_cpus(), physical_cores(), os.cpu_count() or 1
+        sample = ns * rl
+
+        def clocked(fn, threads, target_s, rate1=None):
+            reps = 1 if rate1 is None else max(1, min(64, int(math.ceil(target_s * rate1 * threads * 0.5 / sample))))
+            n, sec = fn(threads, reps)
+            return n, sample * reps / sec / 1e9, reps
+
+        n1, r1, _ = clocked(lambda th, rp: orc.batch_count_clocked(hb, hoff, args.l, args.k, args.density, omode, threads=th, repeats=rp), 1, 0)
+        n2, r2, reps2 = clocked(lambda th, rp: orc.batch_count_clocked(hb, hoff, args.l, args.k, args.density, omode, threads=th, repeats=rp),
+                                ncpu, 3.0, r1 * 1e9)
         assert n1 == n2
         # the reference's own fast path is AVX-512 (HashMode::Simd / HpcSimd): time a restatement of it too, if the host can
         avx = None
@@ -194,24 +334,22 @@ def main():
             av = so.OracleAvx512()
             if av.supported():
                 hp = 1 if mode == pkg.HashMode.Hpc else 0
-                t0 = time.perf_counter()
-                a1 = av.batch_count(hb, hoff, args.l, args.k, args.density, hp, threads=1)
-                ta1 = time.perf_counter() - t0
-                t0 = time.perf_counter()
-                a2 = av.batch_count(hb, hoff, args.l, args.k, args.density, hp, threads=ncpu)
-                ta2 = time.perf_counter() - t0
+                a1, ra1, _ = clocked(lambda th, rp: av.batch_count_clocked(hb, hoff, args.l, args.k, args.density, hp, threads=th, repeats=rp), 1, 0)
+                a2, ra2, repsa = clocked(lambda th, rp: av.batch_count_clocked(hb, hoff, args.l, args.k, args.density, hp, threads=th, repeats=rp),
+                                         ncpu, 3.0, ra1 * 1e9)
                 assert a1 == a2
-                avx = {"mode": "HpcSimd" if hp else "Simd", "value": round(ns * rl / ta1 / 1e9, 4), "cores": 1,
-                       "all_cores": {"value": round(ns * rl / ta2 / 1e9, 4), "cores": ncpu},
+                avx = {"mode": "HpcSimd" if hp else "Simd", "value": round(ra1, 4), "cores": 1,
+                       "all_cores": {"value": round(ra2, 4), "threads": ncpu, "passes": repsa},
                        "note": "oracle/s2k_oracle_avx512.c: restatement of the Simd-mode semantics (strict <, f32 bound), not the reference's code"}
             else:
                 avx = "n/a (host CPU lacks AVX-512 F/BW/VL/VBMI2)"
         except Exception as e:  # the baseline must never break the bench line
             avx = "n/a (%s)" % type(e).__name__
-        cpu = {"value": round(ns * rl / t1 / 1e9, 4), "unit": "Gbp/s", "cores": 1, "kind": "port",
+        cpu = {"value": round(r1, 4), "unit": "Gbp/s", "cores": 1, "kind": "port",
                "sample": "first %d reads (%.2f Gbp) of the same synthetic workload, count-only iteration as in src/main.rs:65-76, "
-                         "oracle/s2k_oracle.c built -O3 -march=native" % (ns, ns * rl / 1e9),
-               "all_cores": {"value": round(ns * rl / t2 / 1e9, 4), "cores": ncpu},
+                         "oracle/s2k_oracle.c built -O3 -march=native; threads created and warmed before the clock starts" % (ns, sample / 1e9),
+               "all_cores": {"value": round(r2, 4), "threads": ncpu, "passes": reps2,
+                             "host": "%d CPUs usable by this process (affinity / cgroup quota) of %d hardware threads, %s physical cores" % (ncpu, nhw, nphys)},
                "avx512": avx,
                "reference_published": "README.md:23: scalar ~0.1-0.2 GB/s, AVX-512 ~1 GB/s per thread (ntHash only, unstated CPU)"}
 
@@ -222,19 +360,16 @@ def main():
             "value": round(value, 2), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%d x %d bp uniform-random ACGT reads per GPU (%.1f Gbp/GPU), HashMode::%s, l=%d k=%d d=%g; "
-                                   "inputs resident in HBM" % (n_reads, rl, n_bases / 1e9, "Hpc" if mode == pkg.HashMode.Hpc else "Regular",
-                                                               args.l, args.k, args.density),
-                       "reads_per_gpu": n_reads, "read_len": rl, "mode": args.mode, "sharding": "reads, contiguous per rank"},
+            "config": dict({"workload": "%s, HashMode::%s, l=%d k=%d d=%g; inputs resident in HBM" % (
+                wl_text, "Hpc" if mode == pkg.HashMode.Hpc else "Regular", args.l, args.k, args.density),
+                "name": "BASELINE configs[1]" if args.workload == "c2" else "BASELINE configs[2]", "mode": args.mode,
+                "largest_shard_over_mean": balance}, **shard_info),
             "counts": {"bases": tot_bases, "minimizers": tot_min, "kminmers": tot_km, "xor_hash_rank0": counts["xor_hash"]},
             "verified_vs_oracle": verified,
-            "other_mode": {"mode": "regular" if args.mode == "hpc" else "hpc",
-                           "value": round(counts2["n_bases"] * world * max(2, args.steps // 2) / dt2 / 1e9, 2), "unit": "Gbp/s",
-                           "kernel_ms": round(min_ms2, 3), "kminmer_kernel_ms": round(km_ms2, 3),
-                           "roofline_frac": round((counts2["n_bases"] + 17 * counts2["n_kminmers"] + 16 * (n_reads + 1)) / (min_ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "other_mode": other_line,
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -153,6 +153,16 @@ s2k_status s2k_sync(s2k_ctx *ctx, s2k_counts *counts);
 s2k_status s2k_hpc_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
                           uint64_t n_bases, uint64_t *d_hpc_off, uint8_t *d_hpc, uint32_t *d_pos,
                           uint64_t capacity, uint64_t *n_runs);
+/* Same with flags.  S2K_HPC_RLE_ALPHABET selects the run rule of `encode_rle` (src/hpc.rs:7-25): a repeated character
+ * collapses only if it is one of "ACTGactgNn" (src/hpc.rs:14); without it any repeated byte collapses (`hpc`
+ * src/hpc.rs:28-41, `encode_rle_simd` src/hpc.rs:44-147).  Not reproduced on the device: the two scalar functions start
+ * from prev_char = '#', so they drop '#' characters that are followed by another character, report a stale position for
+ * the run after a '#', and return "#" for an empty string; here '#' is an ordinary byte and an empty read has no runs
+ * (the host facades add the empty-string case and refuse input that contains '#'). */
+#define S2K_HPC_RLE_ALPHABET 1u
+s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+                             uint64_t n_bases, uint32_t flags, uint64_t *d_hpc_off, uint8_t *d_hpc, uint32_t *d_pos,
+                             uint64_t capacity, uint64_t *n_runs);
 
 /* ---- helpers for device-resident benchmarking ------------------------------------------------- */
 /* Fills d_bases[0..n) with the deterministic synthetic ACGT stream (splitmix64 keyed by seed and

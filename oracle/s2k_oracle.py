@@ -40,6 +40,8 @@ def _ptr(a, t):
 
 class Oracle:
     def __init__(self, path=None, native=False):
+        if path is None and not native and os.environ.get("S2K_ORACLE_LIB"):
+            path = os.environ["S2K_ORACLE_LIB"]  # tests/test_sanitizers.py: the ASan/UBSan build of the same source
         if path is None:
             out = None
             if native:  # -march=native objects must never travel between hosts: key the file by the CPU model

@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libs2k.so")
 ABI_SYMBOLS = [
     "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_strerror",
     "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
-    "s2k_hpc_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
+    "s2k_hpc_device", "s2k_hpc_device_ex", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
 ]
 
 
@@ -37,6 +37,7 @@ class HashMode(enum.IntEnum):  # src/lib.rs:21-27
 
 FLAG_WANT_MINIMIZERS = 1
 FLAG_FORCE_SERIAL = 2
+HPC_RLE_ALPHABET = 1  # s2k_hpc_device_ex: the run rule of encode_rle (src/hpc.rs:14)
 
 
 class S2kError(RuntimeError):
@@ -80,7 +81,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("S2K_LIB") or LIB_PATH  # S2K_LIB: tests load the host-ASan build of the same library
     # One HIP runtime per process: torch bundles its own libamdhip64.so.7 and the system ROCm has
     # another; whichever is mapped first serves both (same SONAME).  Import torch first so that device
     # memory and streams handed over by torch belong to the runtime this library talks to.
@@ -112,6 +113,8 @@ def load_library(path=None):
     L.s2k_sync.argtypes = [C.c_void_p, C.POINTER(Counts)]
     L.s2k_hpc_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.s2k_hpc_device_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.s2k_synth_bases_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
     L.s2k_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.s2k_enable_timing.argtypes = [C.c_void_p, C.c_int]
@@ -201,7 +204,11 @@ class Engine:
         Returns a dict of numpy arrays (copies)."""
         bases = _as_u8(bases)
         read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
-        n_reads = len(read_off) - 1
+        if len(read_off) == 0:
+            raise ValueError("read_off needs n_reads + 1 entries (at least one)")
+        if int(read_off[-1]) > len(bases):
+            raise ValueError("read_off[-1] = %d lies past the end of bases (%d bytes)" % (int(read_off[-1]), len(bases)))
+        n_reads = len(read_off) - 1  # read_off[0] may be > 0: the library rebases the offsets (bases[read_off[0]:read_off[-1]] is used)
         flags = (FLAG_WANT_MINIMIZERS if want_minimizers else 0) | (FLAG_FORCE_SERIAL if force_serial else 0)
         p = Params(int(l), int(k), float(density), int(mode), flags)
         res = Result()
@@ -268,10 +275,12 @@ class Engine:
             self._check(st)
         return st, int(nr.value), int(nb.value)
 
-    def hpc_device(self, d_bases, d_read_off, n_reads, n_bases, d_hpc_off, d_hpc, d_pos, capacity):
+    def hpc_device(self, d_bases, d_read_off, n_reads, n_bases, d_hpc_off, d_hpc, d_pos, capacity, rle=False):
+        """rle=True: the run rule of `encode_rle` (only ACTGactgNn collapse, src/hpc.rs:14); else any repeated byte collapses."""
         n = C.c_uint64(0)
-        st = self.lib.s2k_hpc_device(self.ctx, C.c_void_p(d_bases), C.c_void_p(d_read_off), n_reads, n_bases,
-                                     C.c_void_p(d_hpc_off), C.c_void_p(d_hpc or 0), C.c_void_p(d_pos or 0), capacity, C.byref(n))
+        st = self.lib.s2k_hpc_device_ex(self.ctx, C.c_void_p(d_bases), C.c_void_p(d_read_off), n_reads, n_bases,
+                                        HPC_RLE_ALPHABET if rle else 0, C.c_void_p(d_hpc_off), C.c_void_p(d_hpc or 0),
+                                        C.c_void_p(d_pos or 0), capacity, C.byref(n))
         self._check(st)
         return int(n.value)
 
@@ -378,15 +387,7 @@ class KminmersIterator:
         return KminmerHash(int(r["hash"][i]), int(r["start"][i]), int(r["end"][i]), i, bool(r["rev"][i]))
 
 
-def hpc(seq, engine=None):
-    """Homopolymer-compressed string of one read (any equal bytes collapse): src/hpc.rs:28-41.
-    (The reference's hpc("") returns "#"; an empty read yields an empty string here.)"""
-    s, _ = encode_rle_simd(seq, engine)
-    return s
-
-
-def encode_rle_simd(seq, engine=None):
-    """(compressed string, run-start positions) -- src/hpc.rs:44-147 -- computed on the GPU."""
+def _hpc_gpu(seq, engine, rle):
     import torch
 
     eng = engine or default_engine()
@@ -399,5 +400,37 @@ def encode_rle_simd(seq, engine=None):
     d_h = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
     d_p = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)
-    r = eng.hpc_device(d_b.data_ptr(), d_off.data_ptr(), 1, n, d_ho.data_ptr(), d_h.data_ptr(), d_p.data_ptr(), max(n, 1))
+    r = eng.hpc_device(d_b.data_ptr(), d_off.data_ptr(), 1, n, d_ho.data_ptr(), d_h.data_ptr(), d_p.data_ptr(), max(n, 1), rle=rle)
     return d_h[:r].cpu().numpy().tobytes(), d_p[:r].cpu().numpy().astype(np.uint32)
+
+
+def _no_sentinel(a, who):
+    # hpc / encode_rle start from prev_char = '#' (src/hpc.rs:9,30): a '#' in the input is dropped or misplaces the next
+    # run's position there.  The device op treats '#' as an ordinary byte, so such input is refused instead of answered differently.
+    if len(a) and (a == 0x23).any():
+        raise ValueError("%s: input contains '#', the reference's start sentinel (src/hpc.rs:9,30); not supported" % who)
+
+
+def hpc(seq, engine=None):
+    """Homopolymer-compressed string of one read (any equal characters collapse): src/hpc.rs:28-41, on the GPU.
+    hpc("") == "#" as in the reference (the sentinel is flushed at the end, src/hpc.rs:39-40)."""
+    a = _as_u8(seq)
+    if len(a) == 0:
+        return b"#"
+    _no_sentinel(a, "hpc")
+    return _hpc_gpu(a, engine, False)[0]
+
+
+def encode_rle(seq, engine=None):
+    """(compressed string, run-start positions) with the rule of src/hpc.rs:7-25: only runs of ACTGactgNn collapse
+    (src/hpc.rs:14), every other character stays.  encode_rle("") == ("#", [0]) as in the reference."""
+    a = _as_u8(seq)
+    if len(a) == 0:
+        return b"#", np.zeros(1, dtype=np.uint32)
+    _no_sentinel(a, "encode_rle")
+    return _hpc_gpu(a, engine, True)
+
+
+def encode_rle_simd(seq, engine=None):
+    """(compressed string, run-start positions) -- src/hpc.rs:44-147 (any equal bytes collapse) -- computed on the GPU."""
+    return _hpc_gpu(seq, engine, False)

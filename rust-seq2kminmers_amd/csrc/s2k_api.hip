@@ -176,9 +176,15 @@ s2k_status resolve_sem(s2k_ctx *ctx, const s2k_params *p, Sem *s, uint32_t *boun
     return S2K_OK;
 }
 
+// density as the size estimators use it: NaN -> 0 (as hash_bound does, src/lib.rs:91), clamped to [0, 1]
+double sane_density(double density) {
+    if (!(density == density)) return 0.0;
+    return density < 0 ? 0.0 : (density > 1 ? 1.0 : density);
+}
+
 // expected number of minimizers, padded: canonical min of two strands passes with prob ~ 1-(1-d)^2
 uint64_t pool_estimate(uint64_t n_bases, uint64_t n_units, double density, bool hpc) {
-    double d = density < 0 ? 0 : (density > 1 ? 1 : density);
+    double d = sane_density(density);
     double p = 1.0 - (1.0 - d) * (1.0 - d);
     double est = (double)n_bases * p * (hpc ? 0.85 : 1.0) * 1.15 + 64.0 * sqrt((double)n_bases * p + 1.0);
     uint64_t cap = (uint64_t)est + 4 * n_units + (uint64_t)TILE_BASES + 4096;
@@ -188,7 +194,7 @@ uint64_t pool_estimate(uint64_t n_bases, uint64_t n_units, double density, bool 
 
 // records per tile slab: mean + 6 sigma of a binomial(TILE_BASES, p) + margin
 uint64_t slab_estimate(double density) {
-    double d = density < 0 ? 0 : (density > 1 ? 1 : density);
+    double d = sane_density(density);
     double mu = (double)TILE_BASES * (1.0 - (1.0 - d) * (1.0 - d));
     uint64_t cap = (uint64_t)(mu + 6.0 * sqrt(mu + 1.0)) + 32;
     cap = (cap + 15) & ~(uint64_t)15;
@@ -197,7 +203,7 @@ uint64_t slab_estimate(double density) {
 }
 // overflow region of the tiled path: 2 % of the expected records, at least a few tiles' worth
 uint64_t overflow_estimate(uint64_t n_bases, double density) {
-    double d = density < 0 ? 0 : (density > 1 ? 1 : density);
+    double d = sane_density(density);
     double p = 1.0 - (1.0 - d) * (1.0 - d);
     return (uint64_t)((double)n_bases * p * 0.02) + 4 * (uint64_t)TILE_BASES;
 }
@@ -519,7 +525,9 @@ s2k_status s2k_extract_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64
     c.n_bases = n_bases;
     c.params = *params;
     c.out = *out;
-    if (const char *dbg = getenv("S2K_DEBUG_SKIP")) c.sem.dbg_skip = (uint32_t)atoi(dbg); // ablation timing only
+#ifdef S2K_DEBUG_KNOBS // `make KNOBS=1` / `make PROFILE=1` builds only: ablation timing (results are wrong when set)
+    if (const char *dbg = getenv("S2K_DEBUG_SKIP")) c.sem.dbg_skip = (uint32_t)atoi(dbg);
+#endif
     // the tiled kernel stages tiles with 16 B vector loads: it needs a 16 B aligned base pointer
     c.serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(c.sem) || (((uintptr_t)d_bases) & 15u) != 0;
     c.pool_cap = c.serial ? pool_estimate(n_bases, n_reads, params->density, c.sem.hpc) : overflow_estimate(n_bases, params->density);
@@ -666,7 +674,15 @@ s2k_status s2k_synth_bases_device(s2k_ctx *ctx, uint64_t seed, uint64_t first_ba
 s2k_status s2k_hpc_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
                           uint64_t n_bases, uint64_t *d_hpc_off, uint8_t *d_hpc, uint32_t *d_pos, uint64_t capacity,
                           uint64_t *n_runs) {
+    return s2k_hpc_device_ex(ctx, d_bases, d_read_off, n_reads, n_bases, 0, d_hpc_off, d_hpc, d_pos, capacity, n_runs);
+}
+
+s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+                             uint64_t n_bases, uint32_t flags, uint64_t *d_hpc_off, uint8_t *d_hpc, uint32_t *d_pos,
+                             uint64_t capacity, uint64_t *n_runs) {
     if (!ctx || !d_read_off || !d_hpc_off || (!d_bases && n_bases)) return S2K_ERR_INVALID_ARG;
+    if (flags & ~(uint32_t)S2K_HPC_RLE_ALPHABET) return fail(ctx, S2K_ERR_INVALID_ARG, "unknown s2k_hpc_device_ex flag");
+    const bool rle = (flags & S2K_HPC_RLE_ALPHABET) != 0; // encode_rle: only ACTGactgNn collapse (src/hpc.rs:14)
     S2K_TRY(hipSetDevice(ctx->device), "set device");
     if (ctx->pending) (void)finish(ctx, nullptr);
     // segment-parallel path (16-byte aligned bases, stream starting at offset 0); else one thread per read
@@ -691,17 +707,17 @@ s2k_status s2k_hpc_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *
         }
     }
     if (seg_path) {
-        S2K_TRY(launch_read_run_counts(d_bases, d_read_off, n_reads, n_bases, blk_cnt, blk_off, blk_tmp, cnt, read_c0, ctx->stream),
+        S2K_TRY(launch_read_run_counts(d_bases, d_read_off, n_reads, n_bases, blk_cnt, blk_off, blk_tmp, cnt, read_c0, ctx->stream, rle),
                 "run count kernels");
         S2K_TRY(launch_scan_u32(cnt, n_reads, d_hpc_off, tmp, 0, ctx->stream), "scan");
         if (d_hpc || d_pos)
             S2K_TRY(launch_hpc_segments(d_bases, d_read_off, n_reads, n_bases, d_hpc_off, blk_off, read_c0, d_hpc, d_pos, capacity,
-                                        ctx->stream),
+                                        ctx->stream, rle),
                     "hpc segment kernel");
     } else {
-        S2K_TRY(launch_hpc_count(d_bases, d_read_off, n_reads, cnt, ctx->stream), "hpc count kernel");
+        S2K_TRY(launch_hpc_count(d_bases, d_read_off, n_reads, cnt, ctx->stream, rle), "hpc count kernel");
         S2K_TRY(launch_scan_u32(cnt, n_reads, d_hpc_off, tmp, 0, ctx->stream), "scan");
-        if (d_hpc || d_pos) S2K_TRY(launch_hpc_write(d_bases, d_read_off, n_reads, d_hpc_off, d_hpc, d_pos, capacity, ctx->stream), "hpc write kernel");
+        if (d_hpc || d_pos) S2K_TRY(launch_hpc_write(d_bases, d_read_off, n_reads, d_hpc_off, d_hpc, d_pos, capacity, ctx->stream, rle), "hpc write kernel");
     }
     uint64_t total = 0;
     S2K_TRY(hipMemcpyAsync(&total, d_hpc_off + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H");

@@ -102,17 +102,25 @@ hipError_t launch_scan_u32(const uint32_t *in, uint64_t n, uint64_t *out /*n+1*/
                            uint32_t sub_k /*0: identity, else max(0,x-sub_k+1)*/, hipStream_t st);
 size_t scan_tmp_bytes(uint64_t n);
 
+// encode_rle (src/hpc.rs:7-25) collapses a repeated character only if it is one of "ACTGactgNn" (src/hpc.rs:14); hpc and
+// encode_rle_simd collapse any repeated byte.  `rle` selects the former in the standalone HPC kernels.
+__host__ __device__ inline bool is_rle_char(uint32_t c) {
+    const uint32_t u = c & 0xDFu; // fold case
+    return u == 'A' || u == 'C' || u == 'G' || u == 'T' || u == 'N';
+}
+__host__ __device__ inline bool run_head(uint32_t cur, uint32_t prev, bool rle) { return cur != prev || (rle && !is_rle_char(cur)); }
+
 // runs[r] = number of homopolymer runs of read r (equal adjacent bytes collapse; a read start always begins a run).
 // blk_cnt: n_bases/256+1 u32, blk_off: n_bases/256+2 u64 (prefix of neq-counts per 256-byte block), scan_tmp:
 // scan_tmp_bytes(n_bases/256+1).  read_c0 (optional, n_reads u64): that prefix evaluated at the start of every read.
 hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                   uint32_t *blk_cnt, uint64_t *blk_off, uint64_t *scan_tmp, uint32_t *runs, uint64_t *read_c0,
-                                  hipStream_t st);
+                                  hipStream_t st, bool rle = false);
 // Standalone homopolymer compression, segment-parallel (s2k_hpc_seg.hip): the compressed bytes and read-relative run
 // starts of the whole batch, given hpc_off (= prefix of runs[]), blk_off and read_c0 from launch_read_run_counts.
 hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint8_t *o_hpc,
-                               uint32_t *o_pos, uint64_t capacity, hipStream_t st);
+                               uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle = false);
 
 hipError_t launch_synth(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d, hipStream_t st);
 
@@ -136,9 +144,10 @@ hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off
                                   uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
                                   Counts *counts, hipStream_t st);
 
-hipError_t launch_hpc_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint32_t *run_cnt, hipStream_t st);
+hipError_t launch_hpc_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint32_t *run_cnt, hipStream_t st,
+                            bool rle = false);
 hipError_t launch_hpc_write(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, const uint64_t *hpc_off,
-                            uint8_t *o_hpc, uint32_t *o_pos, uint64_t capacity, hipStream_t st);
+                            uint8_t *o_hpc, uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle = false);
 
 // FASTA/FASTQ record splitting in HBM (s2k_fastx_dev.hip).  count: totals = {records, sequence bytes, syntax errors};
 // write: bases + read_off (n_records + 1 entries).  `ws` holds fx_ws_bytes(n) bytes and must survive both phases.

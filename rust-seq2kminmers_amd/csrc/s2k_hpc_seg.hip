@@ -17,7 +17,7 @@ constexpr uint32_t HS_SEG = HS_THREADS * 16;
 __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
     const uint8_t *__restrict__ s, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
     const uint64_t *__restrict__ hpc_off, const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ read_c0,
-    uint8_t *__restrict__ o_hpc, uint32_t *__restrict__ o_pos, uint64_t capacity) {
+    uint8_t *__restrict__ o_hpc, uint32_t *__restrict__ o_pos, uint64_t capacity, bool rle) {
     __shared__ uint32_t starts[HS_SEG / 32]; // bit i: a non-empty read starts at seg + i
     __shared__ uint32_t ls[HS_THREADS], lm[HS_THREADS];
     __shared__ uint32_t out_p[HS_SEG];
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
         const uint64_t a = read_off[lo];
         uint64_t g = hpc_off[lo];
         if (seg > a) { // runs of that read before the segment
-            const bool neq_a = a == 0 || s[a] != s[a - 1];
+            const bool neq_a = a == 0 || run_head(s[a], s[a - 1], rle);
             g += blk_off[seg / 256] - read_c0[lo] + (neq_a ? 0u : 1u);
         }
         sh_r = lo;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
     uint32_t heads = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        if (j < nval && (c[j] != prev || ((sb >> j) & 1))) heads |= 1u << j;
+        if (j < nval && (prev == 0x100u || run_head(c[j], prev, rle) || ((sb >> j) & 1))) heads |= 1u << j;
         prev = j < nval ? c[j] : prev;
     }
     const uint32_t last_start = sb ? (uint32_t)(16 * t + (31 - __clz(sb)) + 1) : 0u; // segment-relative + 1
@@ -132,11 +132,11 @@ __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
 
 hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint8_t *o_hpc,
-                               uint32_t *o_pos, uint64_t capacity, hipStream_t st) {
+                               uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle) {
     if (n_reads == 0 || n_bases == 0) return hipSuccess;
     const uint64_t segs = (n_bases + HS_SEG - 1) / HS_SEG;
     hipLaunchKernelGGL(hpc_segment_kernel, dim3((unsigned)segs), dim3(HS_THREADS), 0, st, bases, read_off, n_reads, n_bases,
-                       hpc_off, blk_off, read_c0, o_hpc, o_pos, capacity);
+                       hpc_off, blk_off, read_c0, o_hpc, o_pos, capacity, rle);
     return hipGetLastError();
 }
 

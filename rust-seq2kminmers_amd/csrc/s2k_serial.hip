@@ -119,25 +119,25 @@ __global__ __launch_bounds__(64) void serial_write_kernel(const uint8_t *__restr
 // ---- standalone homopolymer compression: hpc() src/hpc.rs:28-41 / encode_rle_simd src/hpc.rs:44-147 ----
 __global__ __launch_bounds__(64) void hpc_count_kernel(const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ read_off, uint64_t n_reads,
-                                                       uint32_t *__restrict__ run_cnt) {
+                                                       uint32_t *__restrict__ run_cnt, bool rle) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     uint64_t a = read_off[r], b = read_off[r + 1];
     uint32_t c = 0;
-    for (uint64_t q = a; q < b; q++) c += (q == a || bases[q] != bases[q - 1]);
+    for (uint64_t q = a; q < b; q++) c += (q == a || run_head(bases[q], bases[q - 1], rle));
     run_cnt[r] = c;
 }
 
 __global__ __launch_bounds__(64) void hpc_write_kernel(const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ read_off, uint64_t n_reads,
                                                        const uint64_t *__restrict__ hpc_off, uint8_t *__restrict__ o_hpc,
-                                                       uint32_t *__restrict__ o_pos, uint64_t capacity) {
+                                                       uint32_t *__restrict__ o_pos, uint64_t capacity, bool rle) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     uint64_t a = read_off[r], b = read_off[r + 1];
     uint64_t o = hpc_off[r];
     for (uint64_t q = a; q < b; q++)
-        if (q == a || bases[q] != bases[q - 1]) {
+        if (q == a || run_head(bases[q], bases[q - 1], rle)) {
             if (o < capacity) {
                 if (o_hpc) o_hpc[o] = bases[q];
                 if (o_pos) o_pos[o] = (uint32_t)(q - a);
@@ -176,15 +176,15 @@ hipError_t launch_serial_write(const uint8_t *bases, const uint64_t *read_off, u
     return hipGetLastError();
 }
 
-hipError_t launch_hpc_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint32_t *run_cnt, hipStream_t st) {
+hipError_t launch_hpc_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint32_t *run_cnt, hipStream_t st, bool rle) {
     if (n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(hpc_count_kernel, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, bases, read_off, n_reads, run_cnt);
+    hipLaunchKernelGGL(hpc_count_kernel, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, bases, read_off, n_reads, run_cnt, rle);
     return hipGetLastError();
 }
 hipError_t launch_hpc_write(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, const uint64_t *hpc_off,
-                            uint8_t *o_hpc, uint32_t *o_pos, uint64_t capacity, hipStream_t st) {
+                            uint8_t *o_hpc, uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle) {
     if (n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(hpc_write_kernel, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, bases, read_off, n_reads, hpc_off, o_hpc, o_pos, capacity);
+    hipLaunchKernelGGL(hpc_write_kernel, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, bases, read_off, n_reads, hpc_off, o_hpc, o_pos, capacity, rle);
     return hipGetLastError();
 }
 

@@ -38,13 +38,15 @@
 //    shared overflow region with one atomic.  (One shared cursor for every tile serialised the kernel.)
 //
 // Diagnostics: S2K_DEBUG_SKIP (bit 1 skip hash loop, 2 skip dense phase, 4 skip compaction, 8 per-phase cycle
-// stamps printed by the host -- only in builds made with `make PROFILE=1` --, 16/32/64 skip stores / per-read counts / re-derivation) and
-// S2K_DEBUG_BLOCKS_PER_CU are timing ablations only -- results are wrong when a skip bit is set.
+// stamps printed by the host -- only in builds made with `make PROFILE=1` --, 16/64 skip stores / re-derivation) and
+// S2K_DEBUG_BLOCKS_PER_CU are timing ablations only -- results are wrong when a skip bit is set.  The library reads
+// these environment variables only when built with `make KNOBS=1` (or PROFILE=1); the shipped build ignores them.
 #pragma once
 #include "s2k_dev.h"
 #include "s2k_static_l.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace s2k {
@@ -1148,11 +1150,14 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
     auto kern = tile_minimizer_kernel<L, HPC>;
     const int lds = block_lds_bytes<HPC>();
     // per instantiation AND per device: function attributes and occupancy belong to the device the module is loaded on
+    // (contexts on different threads may launch concurrently: the cache is filled under a lock)
     constexpr int MAX_DEV = 64;
     static int n_cu_d[MAX_DEV] = {0}, per_cu_d[MAX_DEV] = {0};
+    static std::mutex cache_mu;
     int dev = 0;
     S2K_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEV) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(cache_mu);
     if (n_cu_d[dev] == 0) {
         S2K_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipDeviceProp_t prop;
@@ -1160,7 +1165,9 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
         int occ = 0;
         S2K_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64 * TW, lds));
         per_cu_d[dev] = occ < 1 ? 1 : occ;
-        if (const char *e = getenv("S2K_DEBUG_BLOCKS_PER_CU")) per_cu_d[dev] = atoi(e) > 0 ? atoi(e) : per_cu_d[dev]; // occupancy experiments
+#ifdef S2K_DEBUG_KNOBS // `make KNOBS=1` / `make PROFILE=1` builds only (tools/*.sh): occupancy experiments
+        if (const char *e = getenv("S2K_DEBUG_BLOCKS_PER_CU")) per_cu_d[dev] = atoi(e) > 0 ? atoi(e) : per_cu_d[dev];
+#endif
         n_cu_d[dev] = prop.multiProcessorCount;
     }
     const int n_cu = n_cu_d[dev], per_cu = per_cu_d[dev];

@@ -196,12 +196,12 @@ hipError_t launch_finalize(Counts *counts, const uint64_t *xor_shards, const uin
 namespace {
 constexpr int RUN_BLK = 256;
 
-__global__ __launch_bounds__(256) void run_block_counts(const uint8_t *__restrict__ s, uint64_t n, uint32_t *__restrict__ cnt) {
+__global__ __launch_bounds__(256) void run_block_counts(const uint8_t *__restrict__ s, uint64_t n, uint32_t *__restrict__ cnt, bool rle) {
     const uint64_t q0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; // 16 bytes per thread, 16 threads per block of 256
     uint32_t c = 0;
     if (q0 < n) {
         uint32_t prev = q0 ? s[q0 - 1] : 0x100u;
-        if (q0 + 16 <= n) {
+        if (q0 + 16 <= n && !rle) {
             const uint4 v = *reinterpret_cast<const uint4 *>(s + q0);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(256) void run_block_counts(const uint8_t *__restric
                 prev = w[i] >> 24;
             }
         } else {
-            for (uint64_t q = q0; q < n; q++) {
+            for (uint64_t q = q0; q < n && q < q0 + 16; q++) { // tail of the stream, and the encode_rle flavour
                 const uint32_t b = s[q];
-                c += (prev == 0x100u || b != prev) ? 1u : 0u;
+                c += (prev == 0x100u || run_head(b, prev, rle)) ? 1u : 0u;
                 prev = b;
             }
         }
@@ -230,29 +230,29 @@ __global__ __launch_bounds__(256) void run_block_counts(const uint8_t *__restric
     if ((threadIdx.x & 15) == 0 && blk * RUN_BLK < n + RUN_BLK) cnt[blk] = c;
 }
 
-__device__ inline uint64_t run_prefix(const uint8_t *__restrict__ s, const uint64_t *__restrict__ blk_off, uint64_t b) {
+__device__ inline uint64_t run_prefix(const uint8_t *__restrict__ s, const uint64_t *__restrict__ blk_off, uint64_t b, bool rle) {
     const uint64_t blk = b / RUN_BLK;
     uint64_t c = blk_off[blk];
     uint64_t q = blk * RUN_BLK;
     uint32_t prev = q ? s[q - 1] : 0x100u;
     for (; q < b; q++) {
         const uint32_t v = s[q];
-        c += (prev == 0x100u || v != prev) ? 1u : 0u;
+        c += (prev == 0x100u || run_head(v, prev, rle)) ? 1u : 0u;
         prev = v;
     }
     return c;
 }
 
 __global__ void read_run_counts(const uint8_t *__restrict__ s, const uint64_t *__restrict__ read_off, uint64_t n_reads,
-                                const uint64_t *__restrict__ blk_off, uint32_t *__restrict__ runs, uint64_t *__restrict__ read_c0) {
+                                const uint64_t *__restrict__ blk_off, uint32_t *__restrict__ runs, uint64_t *__restrict__ read_c0, bool rle) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const uint64_t a = read_off[r], b = read_off[r + 1];
     uint32_t R = 0;
-    if (read_c0) read_c0[r] = b > a ? run_prefix(s, blk_off, a) : 0;
+    if (read_c0) read_c0[r] = b > a ? run_prefix(s, blk_off, a, rle) : 0;
     if (b > a) {
-        const uint64_t ca = run_prefix(s, blk_off, a), cb = run_prefix(s, blk_off, b);
-        const bool neq_a = a == 0 || s[a] != s[a - 1];
+        const uint64_t ca = run_prefix(s, blk_off, a, rle), cb = run_prefix(s, blk_off, b, rle);
+        const bool neq_a = a == 0 || run_head(s[a], s[a - 1], rle);
         R = (uint32_t)(cb - ca) + (neq_a ? 0u : 1u);
     }
     runs[r] = R;
@@ -261,15 +261,15 @@ __global__ void read_run_counts(const uint8_t *__restrict__ s, const uint64_t *_
 
 hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                   uint32_t *blk_cnt, uint64_t *blk_off, uint64_t *scan_tmp, uint32_t *runs, uint64_t *read_c0,
-                                  hipStream_t st) {
+                                  hipStream_t st, bool rle) {
     if (n_reads == 0) return hipSuccess;
     const uint64_t nblk = n_bases / RUN_BLK + 1; // the block that holds position n_bases exists too (count 0 past the end)
     const uint64_t threads = nblk * 16;
-    hipLaunchKernelGGL(run_block_counts, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, bases, n_bases, blk_cnt);
+    hipLaunchKernelGGL(run_block_counts, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, bases, n_bases, blk_cnt, rle);
     hipError_t e = launch_scan_u32(blk_cnt, nblk, blk_off, scan_tmp, 0, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(read_run_counts, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, bases, read_off, n_reads,
-                       blk_off, runs, read_c0);
+                       blk_off, runs, read_c0, rle);
     return hipGetLastError();
 }
 

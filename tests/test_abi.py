@@ -48,12 +48,34 @@ def test_no_cpu_fallback_without_gpu():
     assert e.value.status == 8  # S2K_ERR_NO_DEVICE
 
 
-def test_struct_layouts_match_header():
-    # field order / sizes of the ctypes mirrors against the C header (checked through sizeof on this ABI)
-    assert ctypes.sizeof(pkg.Params) == 24
-    assert ctypes.sizeof(pkg.Counts) == 48
-    assert ctypes.sizeof(pkg.DeviceOut) == 88
-    assert ctypes.sizeof(pkg.Result) == 96 + 48 + 8
+def test_struct_layouts_match_header(tmp_path):
+    """A C translation unit that includes include/s2k.h is compiled and run; its sizeof/offsetof of every struct field
+    must equal the ctypes mirrors the tests and bench.py call the library through (and the Rust #[repr(C)] structs of
+    INTEGRATION.md are written against the same table)."""
+    import subprocess
+
+    exe = str(tmp_path / "abi_layout")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "abi_layout.c"), "-o", exe])
+    facts = {}
+    for line in subprocess.check_output([exe], text=True).splitlines():
+        k, *v = line.split()
+        facts[k] = tuple(int(x) for x in v)
+    mirrors = {"s2k_params": pkg.Params, "s2k_counts": pkg.Counts, "s2k_result": pkg.Result, "s2k_device_out": pkg.DeviceOut}
+    for cname, T in mirrors.items():
+        assert facts["sizeof." + cname] == (ctypes.sizeof(T),), cname
+        declared = [k.split(".")[1] for k in facts if k.startswith(cname + ".")]
+        assert declared == [f for f, _ in T._fields_], (cname, declared)  # same fields, same order
+        for f, _ in T._fields_:
+            d = getattr(T, f)
+            assert facts["%s.%s" % (cname, f)] == (d.offset, d.size), (cname, f)
+    HM = pkg.HashMode
+    assert (facts["enum.S2K_MODE_REGULAR"], facts["enum.S2K_MODE_HPC"], facts["enum.S2K_MODE_SIMD"], facts["enum.S2K_MODE_HPCSIMD"]) == \
+        ((int(HM.Regular),), (int(HM.Hpc),), (int(HM.Simd),), (int(HM.HpcSimd),))
+    assert facts["enum.S2K_FLAG_WANT_MINIMIZERS"] == (pkg.FLAG_WANT_MINIMIZERS,) and facts["enum.S2K_FLAG_FORCE_SERIAL"] == (pkg.FLAG_FORCE_SERIAL,)
+    assert facts["enum.S2K_HPC_RLE_ALPHABET"] == (pkg.HPC_RLE_ALPHABET,)
+    assert facts["enum.S2K_ABI_VERSION"] == (pkg.load_library().s2k_abi_version(),)
+    assert facts["enum.S2K_ERR_NO_DEVICE"] == (8,) and facts["enum.S2K_ERR_CAPACITY"] == (7,)
 
 
 def test_kminmerhash_semantics():

@@ -1,0 +1,50 @@
+"""bench.py --gpus N: the launcher starts N rank processes itself; the config-3 workload (`--workload ont`) cuts ONE ragged
+batch into contiguous shards balanced by cumulative bases and every rank runs the HIP path on its shard.  Rehearsed here
+on one GPU (two ranks share device 0, gloo for the count all-reduce): the ranks' outputs, concatenated in rank order,
+must equal the unsharded run (the reference's worker pool, src/main.rs:57,65-79, has the same property per read)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra, tmp, tag):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "ont", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+           "--no-other-mode", "--verify-reads", "50", "--dump-shard", os.path.join(tmp, tag)] + extra
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [x for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, p.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_two_ranks_equal_unsharded(tmp_path):
+    tmp = str(tmp_path)
+    one = run_bench(["--gpus", "1", "--reads", "6000"], tmp, "one")
+    two = run_bench(["--gpus", "2", "--reads", "3000", "--single-device", "--backend", "gloo"], tmp, "two")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["counts"] == {**two["counts"], "xor_hash_rank0": one["counts"]["xor_hash_rank0"]}  # whole-job totals agree
+    assert two["config"]["reads_total"] == 6000 and 1.0 <= two["config"]["largest_shard_over_mean"] < 1.01
+    assert one["verified_vs_oracle"] and two["verified_vs_oracle"]
+    a = np.load(os.path.join(tmp, "one.rank0.npz"))
+    parts = [np.load(os.path.join(tmp, "two.rank%d.npz" % r)) for r in range(2)]
+    assert int(parts[0]["first_base"]) == 0 and int(parts[1]["first_base"]) == int(parts[0]["n_bases"])  # contiguous shards of one stream
+    for f in ("hash", "start", "end", "rev"):
+        assert (np.concatenate([p[f] for p in parts]) == a[f]).all(), f
+    km = np.concatenate([parts[0]["km_off"][:-1], parts[1]["km_off"] + parts[0]["km_off"][-1]])
+    assert (km == a["km_off"]).all()
+
+
+def test_gpus_flag_must_match_world_size():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

@@ -293,6 +293,7 @@ def test_standalone_hpc(eng, oracle, ecoli):
     rs, rp = oracle.hpc(ecoli, 2)
     assert s == rs and (p == rp).all() and len(s) == 72873
     assert pkg.hpc(b"AACCCGTTTTT", engine=eng) == b"ACGT"
+    assert pkg.hpc(ecoli, engine=eng) == oracle.hpc(ecoli, 0)[0]
 
 
 def test_standalone_hpc_batches(eng, oracle):
@@ -338,6 +339,62 @@ def test_standalone_hpc_batches(eng, oracle):
             eng.hpc_device(d_b.data_ptr() + shift, d_o.data_ptr(), len(reads), len(bases), d_ho.data_ptr(), d_h.data_ptr(), d_p.data_ptr(), n // 2)
         assert e.value.status == 7
         assert d_h[:n // 2].cpu().numpy().tobytes() == exp_s[:n // 2] and int(d_h[n // 2:].max().item()) == 0
+
+
+def test_encode_rle_flavour(eng, oracle, ecoli):
+    """encode_rle (src/hpc.rs:7-25): only runs of ACTGactgNn collapse (src/hpc.rs:14), every other repeated character stays;
+    hpc / encode_rle_simd collapse any repeated byte.  GPU ops vs the oracle's restatement of the scalar functions
+    (which = 1 encode_rle, 0 hpc, 2 encode_rle_simd); the empty-string quirk (both scalar functions flush their '#'
+    sentinel, src/hpc.rs:22-24,39-40) lives in the facades; input that contains '#' is refused."""
+    import torch
+
+    rng = np.random.default_rng(43)
+    s, p = pkg.encode_rle(ecoli, engine=eng)  # tests/main.rs:76: encode_rle(s).0 == hpc(s) on the ACGT-only fixture
+    rs, rp = oracle.hpc(ecoli, 1)
+    assert s == rs and (p == rp).all() and len(s) == 72873 and pkg.hpc(ecoli, engine=eng) == s
+    odd = bytearray(rand_read(rng, 40000, hp=0.4, odd=0.0))
+    for i in rng.integers(0, len(odd) - 8, size=600):  # runs of characters outside the alphabet, and of n / lowercase
+        c = int(rng.choice(np.frombuffer(b"XX**--RRnnNNaacc..\x00\x00\xc1\xc1", dtype=np.uint8)))
+        odd[i:i + int(rng.integers(1, 7))] = bytes([c]) * int(rng.integers(1, 7))
+    odd = bytes(odd)
+    for which, fn in ((1, pkg.encode_rle), (2, pkg.encode_rle_simd)):
+        gs, gp = fn(odd, engine=eng)
+        es, ep = oracle.hpc(odd, which)
+        assert gs == es and (gp == ep).all(), which
+    assert pkg.hpc(odd, engine=eng) == oracle.hpc(odd, 0)[0]
+    assert len(pkg.encode_rle(odd, engine=eng)[0]) > len(pkg.encode_rle_simd(odd, engine=eng)[0])  # "XXXX" stays in one, collapses in the other
+    assert pkg.encode_rle(b"AAXXXaaNNnn--A", engine=eng)[0] == b"AXXXaNn--A"
+    # the sentinel quirks
+    assert pkg.hpc(b"", engine=eng) == oracle.hpc(b"", 0)[0] == b"#"
+    es, ep = pkg.encode_rle(b"", engine=eng)
+    assert es == oracle.hpc(b"", 1)[0] == b"#" and list(ep) == [0]
+    for fn in (pkg.hpc, pkg.encode_rle):
+        with pytest.raises(ValueError):
+            fn(b"AC#GT", engine=eng)
+    # batches through s2k_hpc_device_ex: aligned (segment-parallel) and unaligned (read-serial) base pointers
+    dev = torch.device("cuda", 0)
+    lens = [0, 1, 5, 4096, 4097, 9000, 0, 30000] + [int(x) for x in rng.integers(0, 6000, size=80)]
+    reads = [rand_read(rng, n, hp=0.4, odd=0.1) for n in lens]
+    reads[3] = b"X" * 4096                      # never collapses
+    reads[5] = b"n" * 9000                      # collapses to one character
+    reads[7] = b"A" * 10000 + b"-" * 10000 + b"N" * 10000
+    bases, off = pkg.pack_reads(reads)
+    exp = [oracle.hpc(r, 1) if len(r) else (b"", np.zeros(0, dtype=np.uint64)) for r in reads]
+    exp_s = b"".join(e[0] for e in exp)
+    exp_p = np.concatenate([np.asarray(e[1], dtype=np.uint32) for e in exp])
+    exp_off = np.concatenate([[0], np.cumsum([len(e[0]) for e in exp])])
+    for shift in (0, 1):
+        d_b = torch.zeros(len(bases) + 32, dtype=torch.uint8, device=dev)
+        d_b[shift:shift + len(bases)] = torch.from_numpy(bases).to(dev)
+        d_o = torch.from_numpy(off.astype(np.int64)).to(dev)
+        d_ho = torch.zeros(len(reads) + 1, dtype=torch.int64, device=dev)
+        d_h = torch.zeros(len(bases) + 1, dtype=torch.uint8, device=dev)
+        d_p = torch.zeros(len(bases) + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        n = eng.hpc_device(d_b.data_ptr() + shift, d_o.data_ptr(), len(reads), len(bases), d_ho.data_ptr(), d_h.data_ptr(), d_p.data_ptr(),
+                           len(bases), rle=True)
+        assert n == len(exp_s) and (d_ho.cpu().numpy() == exp_off).all()
+        assert d_h[:n].cpu().numpy().tobytes() == exp_s and (d_p[:n].cpu().numpy().view(np.uint32) == exp_p).all()
 
 
 def test_synthetic_config2_sample_properties(eng, oracle):

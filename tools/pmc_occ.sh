@@ -2,6 +2,8 @@
 # tools/pmc_occ.sh: LDS / wait counters of the tiled kernel at 2 and 3 blocks per CU (S2K_DEBUG_BLOCKS_PER_CU)
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_occ
 mkdir -p $out
+# the ablation knobs exist only in KNOBS builds (the copy of the tree on the GPU box is scratch)
+rm -f $GRAFT_REPO_ROOT/rust-seq2kminmers_amd/csrc/*.o && make -s -C $GRAFT_REPO_ROOT/rust-seq2kminmers_amd/csrc KNOBS=1 -j8 libs2k.so > /dev/null 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 for b in 2 3; do
  i=0
