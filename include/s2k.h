@@ -164,6 +164,20 @@ s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_
                              uint64_t n_bases, uint32_t flags, uint64_t *d_hpc_off, uint8_t *d_hpc, uint32_t *d_pos,
                              uint64_t capacity, uint64_t *n_runs);
 
+/* ---- downstream of the path: k-min-mer counting ------------------------------------ */
+/* What the consumer of the iterator does in rust-mdbg (a concurrent map keyed by the k-min-mer hash; the reference only
+ * hints at it, src/lib.rs:256-257; KminmerHash is Eq/Hash by `hash` alone, src/kminmer.rs:181-204): the distinct values
+ * of d_hash[0..n) and how often each occurs.  d_keys / d_counts (either may be NULL) receive up to `capacity` pairs in
+ * unspecified order; *n_distinct is always set (S2K_ERR_CAPACITY when it exceeds capacity). */
+s2k_status s2k_count_device(s2k_ctx *ctx, const uint64_t *d_hash, uint64_t n, uint64_t *d_keys, uint32_t *d_counts,
+                            uint64_t capacity, uint64_t *n_distinct);
+/* Send buffers of the multi-GPU version: d_out = the keys grouped into n_parts ranges of the hash space (part p holds the
+ * hashes h with floor(h * n_parts / 2^64) == p, i.e. split by hash prefix), d_part_off[n_parts + 1] = group starts.  After
+ * an all-to-all of the groups, rank p owns every occurrence of its range and counts locally. */
+#define S2K_MAX_PARTS 64
+s2k_status s2k_partition_device(s2k_ctx *ctx, const uint64_t *d_hash, uint64_t n, uint32_t n_parts, uint64_t *d_out,
+                                uint64_t *d_part_off);
+
 /* ---- helpers for device-resident benchmarking ------------------------------------------------- */
 /* Fills d_bases[0..n) with the deterministic synthetic ACGT stream (splitmix64 keyed by seed and
  * absolute base index; same function as oracle/s2k_oracle.c:s2k_oracle_synth_bases). */

@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libs2k.so")
 ABI_SYMBOLS = [
     "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_strerror",
     "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
-    "s2k_hpc_device", "s2k_hpc_device_ex", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
+    "s2k_hpc_device", "s2k_hpc_device_ex", "s2k_count_device", "s2k_partition_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
 ]
 
 
@@ -115,6 +115,8 @@ def load_library(path=None):
                                  C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.s2k_hpc_device_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.s2k_count_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.s2k_partition_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
     L.s2k_synth_bases_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
     L.s2k_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.s2k_enable_timing.argtypes = [C.c_void_p, C.c_int]
@@ -283,6 +285,20 @@ class Engine:
                                         C.c_void_p(d_pos or 0), capacity, C.byref(n))
         self._check(st)
         return int(n.value)
+
+
+    def count_device(self, d_hash, n, d_keys=0, d_counts=0, capacity=0):
+        """distinct k-min-mer hashes of d_hash[0..n) and their multiplicities (unordered); returns n_distinct"""
+        nd = C.c_uint64(0)
+        st = self.lib.s2k_count_device(self.ctx, C.c_void_p(d_hash or 0), n, C.c_void_p(d_keys or 0), C.c_void_p(d_counts or 0), capacity,
+                                       C.byref(nd))
+        if st != 7 or capacity:
+            self._check(st)
+        return int(nd.value)
+
+    def partition_device(self, d_hash, n, n_parts, d_out, d_part_off):
+        """keys grouped by hash prefix into n_parts ranges (the send buffers of the all-to-all)"""
+        self._check(self.lib.s2k_partition_device(self.ctx, C.c_void_p(d_hash or 0), n, n_parts, C.c_void_p(d_out or 0), C.c_void_p(d_part_off)))
 
 
 class FastxReader:

@@ -83,7 +83,7 @@ struct s2k_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf ws, in_bases, in_off, outbuf;
+    DevBuf ws, in_bases, in_off, outbuf, realign; // realign: aligned copy of a caller's misaligned device stream
     Counts *d_counts = nullptr;
     Counts *h_counts = nullptr; // pinned
     uint64_t *d_xor = nullptr;
@@ -443,6 +443,7 @@ void s2k_destroy(s2k_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->ws.release();
     ctx->in_bases.release();
+    ctx->realign.release();
     ctx->in_off.release();
     ctx->outbuf.release();
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -528,8 +529,15 @@ s2k_status s2k_extract_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64
 #ifdef S2K_DEBUG_KNOBS // `make KNOBS=1` / `make PROFILE=1` builds only: ablation timing (results are wrong when set)
     if (const char *dbg = getenv("S2K_DEBUG_SKIP")) c.sem.dbg_skip = (uint32_t)atoi(dbg);
 #endif
-    // the tiled kernel stages tiles with 16 B vector loads: it needs a 16 B aligned base pointer
-    c.serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(c.sem) || (((uintptr_t)d_bases) & 15u) != 0;
+    c.serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(c.sem);
+    // The tiled kernel stages tiles with 16 B vector loads, i.e. it needs a 16 B aligned base pointer.  A misaligned
+    // stream is first copied to an aligned buffer (one device-to-device pass, ~3 ms per 10 GB) instead of being handed to
+    // the read-serial kernels as in round 1 (20-40x slower for the whole call).
+    if (!c.serial && n_bases && (((uintptr_t)d_bases) & 15u) != 0) {
+        S2K_TRY(ctx->realign.ensure(n_bases + 256), "aligned copy of a misaligned input stream");
+        S2K_TRY(hipMemcpyAsync(ctx->realign.p, d_bases, n_bases, hipMemcpyDeviceToDevice, ctx->stream), "realign copy");
+        c.d_bases = (const uint8_t *)ctx->realign.p;
+    }
     c.pool_cap = c.serial ? pool_estimate(n_bases, n_reads, params->density, c.sem.hpc) : overflow_estimate(n_bases, params->density);
     c.slab_cap = slab_estimate(params->density);
     c.valid = true;
@@ -685,7 +693,12 @@ s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_
     const bool rle = (flags & S2K_HPC_RLE_ALPHABET) != 0; // encode_rle: only ACTGactgNn collapse (src/hpc.rs:14)
     S2K_TRY(hipSetDevice(ctx->device), "set device");
     if (ctx->pending) (void)finish(ctx, nullptr);
-    // segment-parallel path (16-byte aligned bases, stream starting at offset 0); else one thread per read
+    // segment-parallel path: 16-byte vector loads, so a misaligned stream is first copied to an aligned buffer
+    if (n_reads && n_bases && ((uintptr_t)d_bases & 15) != 0) {
+        S2K_TRY(ctx->realign.ensure(n_bases + 256), "aligned copy of a misaligned input stream");
+        S2K_TRY(hipMemcpyAsync(ctx->realign.p, d_bases, n_bases, hipMemcpyDeviceToDevice, ctx->stream), "realign copy");
+        d_bases = (const uint8_t *)ctx->realign.p;
+    }
     const bool seg_path = n_reads && n_bases && ((uintptr_t)d_bases & 15) == 0;
     const uint64_t nblk = n_bases / 256 + 1;
     Arena a{nullptr, 0, 0};

@@ -42,3 +42,61 @@ def allreduce_counts(counts, dist=None, device=None):
     t = torch.tensor([int(counts[k]) for k in COUNT_FIELDS], dtype=torch.int64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return {k: int(v) for k, v in zip(COUNT_FIELDS, t.tolist())}
+
+
+# ---- downstream k-min-mer counting across GPUs: the one place this path has a real exchange step ----
+class EngineCountOps:
+    """partition / count on the GPU through the C ABI (s2k_partition_device / s2k_count_device); tensors are torch CUDA tensors."""
+
+    def __init__(self, eng, device):
+        self.eng, self.device = eng, device
+
+    def partition(self, keys, n_parts):
+        import torch
+
+        out = torch.empty_like(keys)
+        off = torch.zeros(n_parts + 1, dtype=torch.int64, device=self.device)
+        torch.cuda.synchronize(self.device)
+        self.eng.partition_device(keys.data_ptr() if keys.numel() else 0, keys.numel(), n_parts, out.data_ptr() if keys.numel() else 0, off.data_ptr())
+        return out, off.cpu()
+
+    def count(self, keys, want_pairs=False):
+        import torch
+
+        n = keys.numel()
+        torch.cuda.synchronize(self.device)
+        if not want_pairs:
+            return self.eng.count_device(keys.data_ptr() if n else 0, n), None, None
+        k = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        c = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        nd = self.eng.count_device(keys.data_ptr() if n else 0, n, k.data_ptr(), c.data_ptr(), max(n, 1))
+        return nd, k[:nd], c[:nd]
+
+
+def count_kminmers(keys, ops, dist=None, collectives_on_device=True, want_pairs=False):
+    """Distinct k-min-mer hashes and their multiplicities over ALL ranks.  `keys`: this rank's k-min-mer hashes (int64 view of
+    the u64 values).  One rank: count locally.  Several: every rank splits its keys by hash prefix into world_size groups,
+    one all-to-all (RCCL when the tensors live on the GPU) moves group p to rank p, which then owns every occurrence of its
+    range of the hash space and counts it; the totals are summed with an all-reduce.
+    Returns dict(n_keys, n_distinct, n_distinct_local, keys, counts) -- keys/counts are this rank's range (want_pairs)."""
+    import torch
+
+    world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+    if world == 1:
+        nd, k, c = ops.count(keys, want_pairs)
+        return {"n_keys": int(keys.numel()), "n_distinct": nd, "n_distinct_local": nd, "keys": k, "counts": c}
+    grouped, off = ops.partition(keys, world)
+    send = (off[1:] - off[:-1]).to(torch.int64)
+    cdev = keys.device if collectives_on_device else torch.device("cpu")
+    send_c = send.to(cdev)
+    recv_c = torch.empty_like(send_c)
+    dist.all_to_all_single(recv_c, send_c)  # how many keys come from each rank
+    recv = recv_c.cpu()
+    src = grouped if collectives_on_device else grouped.cpu()
+    got = torch.empty(int(recv.sum()), dtype=keys.dtype, device=cdev)
+    dist.all_to_all_single(got, src, output_split_sizes=[int(x) for x in recv], input_split_sizes=[int(x) for x in send])
+    got = got.to(keys.device)
+    nd, k, c = ops.count(got, want_pairs)
+    t = torch.tensor([int(keys.numel()), nd], dtype=torch.int64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return {"n_keys": int(t[0]), "n_distinct": int(t[1]), "n_distinct_local": nd, "keys": k, "counts": c, "n_received": int(got.numel())}

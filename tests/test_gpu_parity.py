@@ -158,6 +158,21 @@ def test_odd_bytes(eng, oracle):
     compare(eng, oracle, reads, 31, 5, 0.05, HM.HpcSimd, expect_path=0, tag="hibit")
 
 
+def test_one_high_byte_does_not_change_the_path(eng, oracle):
+    """Round 1 sent a whole Hpc call to the read-serial kernels when a single byte >= 0x80 appeared anywhere in it (the
+    staged bytes carried read-start marks in bit 7).  Now such a byte is an ordinary 'other' byte: the call stays on the
+    tiled kernels (counts.path == 0) and agrees with the oracle and with the serial kernels."""
+    rng = np.random.default_rng(77)
+    reads = [rand_read(rng, int(n), hp=0.2) for n in rng.integers(5000, 40000, size=300)]
+    dirty = bytearray(reads[137])
+    dirty[len(dirty) // 2] = 0xC1
+    reads[137] = bytes(dirty)
+    for mode in (HM.Hpc, HM.HpcSimd):
+        a = compare(eng, oracle, reads, 31, 10, 0.01, mode, expect_path=0, tag="one-high-byte")
+        b = compare(eng, oracle, reads, 31, 10, 0.01, mode, force_serial=True, expect_path=1, tag="one-high-byte-serial")
+        assert a["n"] == b["n"] and (a["hash"] == b["hash"]).all()
+
+
 def test_simd_result_semantics(eng, oracle):
     """SURVEY.md 8a traps (i)-(vi): strict '<', f32 bound, kept last l-mer, start-of-run end, low-nibble
     seeds, dropped final 16-block when #l-mers % 16 == 0."""
@@ -264,13 +279,18 @@ def test_device_api_capacity_and_async(eng, oracle):
     assert (t["km_off"].cpu().numpy().view(np.uint64) == ref["km_off"]).all()
     assert (t["start"].cpu().numpy().view(np.uint32) == ref["start"]).all()
     assert (t["rev"].cpu().numpy() == ref["rev"]).all()
-    # unaligned base pointer -> serial path, same answer
-    d_b2 = torch.zeros(len(bases) + 1, dtype=torch.uint8, device=dev)
-    d_b2[1:] = d_b
-    torch.cuda.synchronize()
-    t, o = mk(nk)
-    c = eng.extract_device(d_b2.data_ptr() + 1, d_o.data_ptr(), len(reads), len(bases), 31, 10, 0.01, 0, o)
-    assert c["path"] == 1 and (t["hash"].cpu().numpy().view(np.uint64) == ref["hash"]).all()
+    # misaligned base pointers stay on the tiled kernels (the library realigns the stream with one device copy), same answer
+    for shift in (1, 7, 15):
+        d_b2 = torch.zeros(len(bases) + 16, dtype=torch.uint8, device=dev)
+        d_b2[shift:shift + len(bases)] = d_b
+        torch.cuda.synchronize()
+        for m in (0, 1):
+            refm = ref if m == 0 else oracle.batch(bases, off, 31, 10, 0.01, 1)
+            t, o = mk(max(refm["n"], 1))
+            c = eng.extract_device(d_b2.data_ptr() + shift, d_o.data_ptr(), len(reads), len(bases), 31, 10, 0.01, m, o)
+            assert c["path"] == 0 and c["n_kminmers"] == refm["n"]
+            assert (t["hash"][:refm["n"]].cpu().numpy().view(np.uint64) == refm["hash"]).all()
+            assert (t["end"][:refm["n"]].cpu().numpy().view(np.uint32) == refm["end"]).all()
 
 
 def test_synth_generator_matches_oracle(eng, oracle):
