@@ -576,7 +576,9 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
     S2K_TRY(ctx->in_off.ensure((n_reads + 1) * sizeof(uint64_t)), "input allocation");
     std::vector<uint64_t> off(n_reads + 1);
     for (uint64_t r = 0; r <= n_reads; r++) off[r] = read_off[r] - first;
-    S2K_TRY(ctx->stager.h2d(ctx->in_bases.p, bases + first, n_bases, ctx->stream), "H2D bases");
+    // bases cross PCIe packed to 2 bits (exact: every non-ACGT byte travels in a side list), unless the caller opts out
+    if (params->flags & S2K_FLAG_NO_PACK2) S2K_TRY(ctx->stager.h2d(ctx->in_bases.p, bases + first, n_bases, ctx->stream), "H2D bases");
+    else S2K_TRY(ctx->stager.h2d_packed(ctx->in_bases.p, bases + first, n_bases, ctx->stream), "H2D bases (2-bit packed)");
     S2K_TRY(hipMemcpyAsync(ctx->in_off.p, off.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream), "H2D offsets");
     S2K_TRY(hipStreamSynchronize(ctx->stream), "H2D sync");
 

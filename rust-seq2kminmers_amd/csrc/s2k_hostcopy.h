@@ -23,7 +23,8 @@ public:
     ~CopyPool();
     void copy(void *dst, const void *src, size_t bytes); // returns when done
     // runs fn(begin, end) on 4 KiB-aligned slices of [0, bytes), one slice per thread; returns when all are done
-    void slices(size_t bytes, const std::function<void(size_t, size_t)> &fn);
+    // (max_parts > 0 limits the number of threads that take part: a plain copy saturates the link with 8)
+    void slices(size_t bytes, const std::function<void(size_t, size_t)> &fn, int max_parts = 0);
     int threads() const { return (int)workers_.size() + 1; }
 
 private:
@@ -36,6 +37,7 @@ private:
     bool stop_ = false;
     const std::function<void(size_t, size_t)> *fn_ = nullptr;
     size_t bytes_ = 0;
+    int parts_ = 1;
 };
 
 class HostStager {
@@ -51,6 +53,12 @@ public:
     // [offset, offset+n) to pinned_dst (called from several threads on disjoint ranges); false aborts.
     hipError_t h2d_fill(void *dst_dev, size_t bytes, hipStream_t s,
                         const std::function<bool(char *, size_t, size_t)> &fill);
+    // pageable host -> device for DNA text: the copy threads pack the bases to 2 bits ("ACTG"[(b >> 1) & 3], four bases
+    // per byte) while they fill the pinned chunk, every byte that is not one of A C G T goes to a side list of
+    // (position, byte) exceptions, a quarter of the bytes crosses PCIe, and two small kernels on `s` rebuild the exact
+    // ASCII stream in dst_dev (which must be 16-byte aligned).  A chunk with more than ~3 % exceptions (lower-case text,
+    // quality strings ...) is sent as it is.  SURVEY.md 8f-1: "host-side 2-bit packing to cut PCIe bytes 4x".
+    hipError_t h2d_packed(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);
     // device -> pageable host, ordered after the work already queued on `s`.  On return `dst` is complete.
     hipError_t d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
 
@@ -61,6 +69,7 @@ public:
 private:
     hipError_t init();
     bool ready_ = false;
+    char *dpack_[kSlots] = {}; // device staging of the packed chunks (h2d_packed)
     char *pin_[kSlots] = {};
     hipEvent_t ev_[kSlots] = {};
     CopyPool *pool_ = nullptr;

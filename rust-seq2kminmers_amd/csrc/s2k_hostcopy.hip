@@ -4,6 +4,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <immintrin.h>
+#include <sched.h>
 
 namespace s2k {
 
@@ -33,6 +35,7 @@ void CopyPool::worker(int idx) {
     for (;;) {
         const std::function<void(size_t, size_t)> *fn;
         size_t n;
+        int parts;
         {
             std::unique_lock<std::mutex> g(m_);
             cv_.wait(g, [&] { return gen_ != seen; });
@@ -40,9 +43,10 @@ void CopyPool::worker(int idx) {
             if (stop_) return;
             fn = fn_;
             n = bytes_;
+            parts = parts_;
         }
-        size_t b, e;
-        slice_of(n, threads(), idx, &b, &e);
+        size_t b = 0, e = 0;
+        if (idx < parts) slice_of(n, parts, idx, &b, &e);
         if (e > b) (*fn)(b, e);
         {
             std::lock_guard<std::mutex> g(m_);
@@ -51,8 +55,9 @@ void CopyPool::worker(int idx) {
     }
 }
 
-void CopyPool::slices(size_t bytes, const std::function<void(size_t, size_t)> &fn) {
+void CopyPool::slices(size_t bytes, const std::function<void(size_t, size_t)> &fn, int max_parts) {
     const int T = threads();
+    const int parts = max_parts > 0 && max_parts < T ? max_parts : T;
     if (T == 1 || bytes < (256u << 10)) {
         if (bytes) fn(0, bytes);
         return;
@@ -61,19 +66,20 @@ void CopyPool::slices(size_t bytes, const std::function<void(size_t, size_t)> &f
         std::lock_guard<std::mutex> g(m_);
         fn_ = &fn;
         bytes_ = bytes;
+        parts_ = parts;
         remaining_ = T - 1;
         gen_++;
     }
     cv_.notify_all();
     size_t b, e;
-    slice_of(bytes, T, 0, &b, &e);
+    slice_of(bytes, parts, 0, &b, &e);
     if (e > b) fn(b, e);
     std::unique_lock<std::mutex> g(m_);
     done_cv_.wait(g, [&] { return remaining_ == 0; });
 }
 
 void CopyPool::copy(void *dst, const void *src, size_t bytes) {
-    slices(bytes, [&](size_t b, size_t e) { memcpy((char *)dst + b, (const char *)src + b, e - b); });
+    slices(bytes, [&](size_t b, size_t e) { memcpy((char *)dst + b, (const char *)src + b, e - b); }, 8);
 }
 
 HostStager::~HostStager() {
@@ -83,6 +89,7 @@ HostStager::~HostStager() {
             (void)hipEventDestroy(ev_[i]);
         }
         if (pin_[i]) (void)hipHostFree(pin_[i]);
+        if (dpack_[i]) (void)hipFree(dpack_[i]);
     }
     delete pool_;
 }
@@ -101,8 +108,10 @@ hipError_t HostStager::init() {
         int t = 0;
         if (const char *v = getenv("S2K_COPY_THREADS")) t = atoi(v);
         if (t <= 0) {
-            const unsigned hw = std::thread::hardware_concurrency();
-            t = hw >= 16 ? 8 : hw >= 4 ? (int)hw / 2 : 1;
+            unsigned hw = std::thread::hardware_concurrency();
+            cpu_set_t set; // the CPUs this process may use (a 1-GPU job gets a share of the host)
+            if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && (unsigned)CPU_COUNT(&set) < hw) hw = (unsigned)CPU_COUNT(&set);
+            t = hw >= 16 ? 16 : hw >= 4 ? (int)hw / 2 : 1; // packing bases to 2 bits is compute: it scales past the 8 threads a plain copy needs
         }
         pool_ = new CopyPool(t);
     }
@@ -138,7 +147,7 @@ hipError_t HostStager::h2d_fill(void *dst_dev, size_t bytes, hipStream_t s,
         char *pin = pin_[slot];
         pool_->slices(n, [&](size_t b, size_t en) {
             if (!fill(pin + b, off + b, en - b)) ok = false;
-        });
+        }, 8);
         if (!ok) return hipErrorUnknown;
         if ((e = hipMemcpyAsync((char *)dst_dev + off, pin, n, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev_[slot], s)) != hipSuccess) return e;
@@ -172,6 +181,156 @@ hipError_t HostStager::d2h(void *dst_host, const void *src_dev, size_t bytes, hi
         if ((e = hipEventSynchronize(ev_[slot])) != hipSuccess) return e;
         pool_->copy((char *)dst_host + off, pin_[slot], n);
         if (c + kSlots < chunks && (e = issue(c + kSlots)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+
+// ---- 2-bit packed transfers ----------------------------------------------------------------------------------------
+namespace {
+
+struct Exc { // a byte of the stream that is not one of A C G T
+    uint32_t pos;  // offset inside the chunk
+    uint32_t byte;
+};
+
+// code of a base = (ascii >> 1) & 3: A 0, C 1, T 2, G 3
+inline int base_code(uint8_t b) { return (b == 'A' || b == 'C' || b == 'G' || b == 'T') ? ((b >> 1) & 3) : -1; }
+
+// packs src[0..n) (n % 4 == 0 except for the very last slice of a stream) into dst[0..ceil(n/4)); exceptions go to
+// exc[0..cap) with positions chunk_off + i; returns their number, or SIZE_MAX when there are more than cap
+size_t pack2_scalar(const uint8_t *src, size_t n, uint8_t *dst, Exc *exc, size_t cap, uint32_t chunk_off, size_t ne) {
+    for (size_t i = 0; i < n; i += 4) {
+        uint32_t v = 0;
+        for (size_t j = 0; j < 4 && i + j < n; j++) {
+            int c = base_code(src[i + j]);
+            if (c < 0) {
+                if (ne >= cap) return SIZE_MAX;
+                exc[ne++] = Exc{chunk_off + (uint32_t)(i + j), src[i + j]};
+                c = 0;
+            }
+            v |= (uint32_t)c << (2 * j);
+        }
+        dst[i / 4] = (uint8_t)v;
+    }
+    return ne;
+}
+
+__attribute__((target("avx2,bmi2"))) size_t pack2_avx2(const uint8_t *src, size_t n, uint8_t *dst, Exc *exc, size_t cap,
+                                                        uint32_t chunk_off) {
+    const __m256i lut = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                         0, 0, 0);
+    const __m256i m6 = _mm256_set1_epi8(6);
+    size_t ne = 0, i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)(src + i));
+        const __m256i c2 = _mm256_and_si256(v, m6);                    // code << 1
+        const __m256i idx = _mm256_srli_epi16(c2, 1);                  // bit 0 of every byte of c2 is clear: no cross-byte spill
+        const __m256i expect = _mm256_shuffle_epi8(lut, idx);
+        if (_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, expect)) == -1) { // all 32 are A C G T
+            const uint64_t m = 0x0606060606060606ull;
+            const uint64_t a = _pext_u64((uint64_t)_mm256_extract_epi64(v, 0), m), b = _pext_u64((uint64_t)_mm256_extract_epi64(v, 1), m);
+            const uint64_t c = _pext_u64((uint64_t)_mm256_extract_epi64(v, 2), m), d = _pext_u64((uint64_t)_mm256_extract_epi64(v, 3), m);
+            const uint64_t w = a | (b << 16) | (c << 32) | (d << 48);
+            memcpy(dst + i / 4, &w, 8);
+        } else {
+            ne = pack2_scalar(src + i, 32, dst + i / 4, exc, cap, chunk_off + (uint32_t)i, ne);
+            if (ne == SIZE_MAX) return SIZE_MAX;
+        }
+    }
+    if (i < n) ne = pack2_scalar(src + i, n - i, dst + i / 4, exc, cap, chunk_off + (uint32_t)i, ne);
+    return ne;
+}
+
+size_t pack2(const uint8_t *src, size_t n, uint8_t *dst, Exc *exc, size_t cap, uint32_t chunk_off) {
+    static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+    return fast ? pack2_avx2(src, n, dst, exc, cap, chunk_off) : pack2_scalar(src, n, dst, exc, cap, chunk_off, 0);
+}
+
+// 16 bases per thread: 4 packed bytes -> 16 ASCII bytes ("ACTG"[code])
+__global__ __launch_bounds__(256) void unpack2_kernel(const uint32_t *__restrict__ packed, uint64_t n_bases, uint8_t *__restrict__ out) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; // group of 16 bases
+    if (g * 16 >= n_bases) return;
+    const uint32_t p = packed[g];
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b = (p >> (8 * k)) & 0xFFu;
+        const uint32_t sel = (b & 3u) | ((b & 0xCu) << 6) | ((b & 0x30u) << 12) | ((b & 0xC0u) << 18); // one code per selector byte
+        w[k] = __builtin_amdgcn_perm(0u, 0x47544341u /* "ACTG" */, sel);
+    }
+    if (g * 16 + 16 <= n_bases) *reinterpret_cast<uint4 *>(out + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    else
+        for (uint64_t i = g * 16; i < n_bases; i++) out[i] = (uint8_t)(w[(i >> 2) & 3] >> (8 * (i & 3)));
+}
+__global__ __launch_bounds__(256) void patch_exceptions_kernel(const Exc *__restrict__ exc, uint32_t n, uint8_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[exc[i].pos] = (uint8_t)exc[i].byte;
+}
+
+} // namespace
+
+hipError_t HostStager::h2d_packed(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) {
+    if (bytes < (8u << 20) || ((uintptr_t)dst_dev & 15u) != 0) return h2d(dst_dev, src_host, bytes, s);
+    hipError_t e = init();
+    if (e != hipSuccess) return e;
+    constexpr size_t kHalf = kChunk / 2;  // pinned chunk = [packed bases | exception lists]
+    constexpr size_t kSrc = 4 * kHalf;    // source bytes per chunk (64 MiB)
+    for (int i = 0; i < kSlots; i++)
+        if (!dpack_[i] && (e = hipMalloc((void **)&dpack_[i], kChunk)) != hipSuccess) return e;
+    const uint8_t *src = (const uint8_t *)src_host;
+    size_t off = 0;
+    for (int i = 0; off < bytes; i++) {
+        const int slot = i % kSlots;
+        const size_t n = bytes - off < kSrc ? bytes - off : kSrc;
+        if ((e = hipEventSynchronize(ev_[slot])) != hipSuccess) return e;
+        char *pin = pin_[slot];
+        std::atomic<bool> overflow{false};
+        // every slice packs its part and keeps its exceptions in the matching part of the second half: [count u64][entries]
+        pool_->slices(n, [&](size_t b, size_t en) {
+            char *region = pin + kHalf + b / 4;
+            const size_t cap = (en - b) / 4 >= 16 ? ((en - b) / 4 - 8) / sizeof(Exc) : 0;
+            const size_t ne = pack2(src + off + b, en - b, (uint8_t *)pin + b / 4, (Exc *)(region + 8), cap, (uint32_t)b);
+            if (ne == SIZE_MAX) overflow = true;
+            else memcpy(region, &ne, 8);
+        });
+        if (overflow) { // not DNA text: this chunk goes as it is (two pinned chunks' worth at most)
+            if ((e = hipEventRecord(ev_[slot], s)) != hipSuccess) return e;
+            if ((e = h2d((char *)dst_dev + off, src + off, n, s)) != hipSuccess) return e;
+            off += n;
+            continue;
+        }
+        // gather the slices' exception lists behind the packed bytes (few entries; one thread)
+        size_t n_exc = 0;
+        {
+            const int T = pool_->threads();
+            Exc *all = (Exc *)(pin + kHalf);
+            std::vector<Exc> tmp;
+            for (int t = 0; t < (n < (256u << 10) ? 1 : T); t++) {
+                size_t b, en;
+                if (n < (256u << 10)) { b = 0; en = n; }
+                else slice_of(n, T, t, &b, &en);
+                if (en <= b) continue;
+                size_t ne;
+                memcpy(&ne, pin + kHalf + b / 4, 8);
+                const Exc *list = (const Exc *)(pin + kHalf + b / 4 + 8);
+                tmp.insert(tmp.end(), list, list + ne);
+            }
+            n_exc = tmp.size();
+            if (n_exc) memcpy(all, tmp.data(), n_exc * sizeof(Exc));
+        }
+        const size_t packed_bytes = (n + 3) / 4;
+        if ((e = hipMemcpyAsync(dpack_[slot], pin, (packed_bytes + 3) & ~(size_t)3, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+        if (n_exc && (e = hipMemcpyAsync(dpack_[slot] + kHalf, pin + kHalf, n_exc * sizeof(Exc), hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev_[slot], s)) != hipSuccess) return e;
+        const uint64_t groups = (n + 15) / 16;
+        hipLaunchKernelGGL(unpack2_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, (const uint32_t *)dpack_[slot], (uint64_t)n,
+                           (uint8_t *)dst_dev + off);
+        if (n_exc)
+            hipLaunchKernelGGL(patch_exceptions_kernel, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, s, (const Exc *)(dpack_[slot] + kHalf),
+                               (uint32_t)n_exc, (uint8_t *)dst_dev + off);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        off += n;
     }
     return hipSuccess;
 }

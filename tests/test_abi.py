@@ -73,7 +73,7 @@ def test_struct_layouts_match_header(tmp_path):
     assert (facts["enum.S2K_MODE_REGULAR"], facts["enum.S2K_MODE_HPC"], facts["enum.S2K_MODE_SIMD"], facts["enum.S2K_MODE_HPCSIMD"]) == \
         ((int(HM.Regular),), (int(HM.Hpc),), (int(HM.Simd),), (int(HM.HpcSimd),))
     assert facts["enum.S2K_FLAG_WANT_MINIMIZERS"] == (pkg.FLAG_WANT_MINIMIZERS,) and facts["enum.S2K_FLAG_FORCE_SERIAL"] == (pkg.FLAG_FORCE_SERIAL,)
-    assert facts["enum.S2K_HPC_RLE_ALPHABET"] == (pkg.HPC_RLE_ALPHABET,)
+    assert facts["enum.S2K_HPC_RLE_ALPHABET"] == (pkg.HPC_RLE_ALPHABET,) and facts["enum.S2K_FLAG_NO_PACK2"] == (pkg.FLAG_NO_PACK2,)
     assert facts["enum.S2K_ABI_VERSION"] == (pkg.load_library().s2k_abi_version(),)
     assert facts["enum.S2K_ERR_NO_DEVICE"] == (8,) and facts["enum.S2K_ERR_CAPACITY"] == (7,)
 

@@ -173,6 +173,35 @@ def test_one_high_byte_does_not_change_the_path(eng, oracle):
         assert a["n"] == b["n"] and (a["hash"] == b["hash"]).all()
 
 
+def test_packed_host_transfer_is_exact(eng, oracle):
+    """s2k_extract sends the bases 2-bit packed over PCIe (copy threads pack while they fill the pinned ring; every byte that
+    is not A/C/G/T travels in an exception list; a chunk that is mostly not DNA text goes as it is).  The stream rebuilt on
+    the device must be the caller's bytes exactly: results equal the oracle's and the unpacked path's, on a batch that spans
+    two 64 MiB chunks and holds N runs, odd bytes, bytes >= 0x80 and a lower-case stretch longer than a packing slice."""
+    rng = np.random.default_rng(91)
+    n = (64 << 20) + 5_000_000
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+    for a in rng.integers(0, n - 100, size=3000):
+        s[a:a + int(rng.integers(1, 40))] = ord("N")
+    odd = rng.integers(0, n, size=20000)
+    s[odd] = np.frombuffer(b"nacgtXR*-\xc1\x00", dtype=np.uint8)[rng.integers(0, 11, size=len(odd))]
+    s[(64 << 20) + 100_000:(64 << 20) + 4_600_000] |= 0x20  # lower case: more exceptions than a slice's list holds
+    lens = []
+    while sum(lens) < n:
+        lens.append(int(rng.integers(2000, 60000)))
+    off = np.minimum(np.concatenate([[0], np.cumsum(lens)]), n).astype(np.uint64)
+    ref = oracle.batch(s, off, 31, 10, 0.01, 0, threads=4)
+    for pack2 in (True, False):
+        got = eng.extract(s, off, 31, 10, 0.01, HM.Regular, pack2=pack2)
+        assert got["counts"]["path"] == 0 and got["n"] == ref["n"], pack2
+        for f in FIELDS:
+            assert (got[f] == ref[f]).all(), (pack2, f)
+    refh = oracle.batch(s[: 20_000_000], off[: int(np.searchsorted(off, 20_000_000))], 31, 10, 0.01, 1, threads=4)
+    nr = len(off[: int(np.searchsorted(off, 20_000_000))]) - 1
+    goth = eng.extract(s, off[: nr + 1], 31, 10, 0.01, HM.Hpc)
+    assert goth["n"] == refh["n"] and (goth["hash"] == refh["hash"]).all() and (goth["end"] == refh["end"]).all()
+
+
 def test_simd_result_semantics(eng, oracle):
     """SURVEY.md 8a traps (i)-(vi): strict '<', f32 bound, kept last l-mer, start-of-run end, low-nibble
     seeds, dropped final 16-block when #l-mers % 16 == 0."""

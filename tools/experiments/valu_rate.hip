@@ -15,16 +15,16 @@
         uint32_t a0 = threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17,   \
                  a7 = a0 * 19;                                                                          \
         uint32_t b = s ^ threadIdx.x, c = s + 7;                                                        \
-        uint64_t t0 = __builtin_amdgcn_s_memtime();                                                     \
+        uint64_t t0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();                                \
         for (int i = 0; i < iters; i++) {                                                               \
             BODY4(asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                   \
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
                                : "v"(b), "v"(c), "s"(s)                                                 \
                                : __VA_ARGS__);)                                                                \
         }                                                                                               \
-        uint64_t t1 = __builtin_amdgcn_s_memtime();                                                     \
+        uint64_t t1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();                                \
         out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                     \
-        if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;                                                \
+        if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; cyc[gridDim.x + blockIdx.x] = w1 - w0; }                                                \
     }
 
 #define A_XOR(i) "v_xor_b32 %" #i ", %" #i ", %8\n\t"
@@ -151,8 +151,8 @@ int main() {
     uint64_t *d_cyc;
     const int max_blocks = n_cu * 8;
     hipMalloc(&d_out, (size_t)max_blocks * 256 * 4);
-    hipMalloc(&d_cyc, (size_t)max_blocks * 8);
-    std::vector<uint64_t> h(max_blocks);
+    hipMalloc(&d_cyc, (size_t)max_blocks * 16);
+    std::vector<uint64_t> h(2 * max_blocks);
     Test tests[] = {{"v_xor_b32", k_xor, 32}, {"v_alignbit_b32", k_alignbit, 32}, {"v_min_u32", k_min, 32}, {"v_add_u32", k_add, 32},
                     {"v_cndmask_b32(vcc)", k_cndmask, 32}, {"v_addc_co_u32", k_addc, 32}, {"v_cmp_ge_u32", k_cmp, 32},
                     {"v_lshlrev_b32_sdwa", k_sdwa, 32}, {"v_fma_f32", k_fma, 32}, {"v_and_or_b32", k_andor, 32},
@@ -185,13 +185,13 @@ int main() {
             hipDeviceSynchronize();
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
-            hipMemcpy(h.data(), d_cyc, (size_t)blocks * 8, hipMemcpyDeviceToHost);
-            double avg = 0;
-            for (int i = 0; i < blocks; i++) avg += (double)h[i];
-            avg /= blocks;
+            hipMemcpy(h.data(), d_cyc, (size_t)blocks * 16, hipMemcpyDeviceToHost);
+            double avg = 0, wavg = 0;
+            for (int i = 0; i < blocks; i++) { avg += (double)h[i]; wavg += (double)h[blocks + i]; }
+            avg /= blocks; wavg /= blocks;
             const double instrs = (double)iters * t.ops_per_body;
             printf("  %7.2f", avg / (instrs * wps));
-            if (wps == 8) printf("   [%.3f ms wall -> %.2f cyc at 2.4 GHz]", ms, ms * 1e-3 * 2.4e9 / (instrs * wps));
+            if (wps == 8) printf("   [%.3f ms wall; block alive %.3f ms (100 MHz clock); shader clock %.0f MHz]", ms, wavg / 1e5, avg / wavg * 100.0);
         }
         printf("\n");
         fflush(stdout);

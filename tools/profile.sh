@@ -1,46 +1,63 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/profile.sh <tag>
-# 1. rocprofv3 --kernel-trace --stats of the default bench command  -> gpurun_out/prof_<tag>/stats
-# 2. separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) on the same workload -> gpurun_out/prof_<tag>/pmc
+# For each scalar HashMode (hpc = the headline, regular):
+#  1. rocprofv3 --kernel-trace --stats of the bench command            -> gpurun_out/prof_<tag>/<mode>/stats
+#  2. separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ sets), kernel-trace only, as the pool requires -> .../pmc
+# and a traffic.json with the HBM bytes of ALL kernels of a step (FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md, WRITE_SIZE exact).
 tag=$1
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --verify-reads 0 > $out/stats.log 2>&1 || echo "stats pass failed"
-i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES" "GRBM_GUI_ACTIVE"; do
-  i=$((i+1))
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --verify-reads 0 > $out/pmc_p$i.log 2>&1 || echo "pmc pass $i failed"
+for mode in hpc regular; do
+  args="--mode $mode --no-other-mode --no-cpu-baseline --verify-reads 0"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$mode/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $args > $out/$mode.stats.log 2>&1 || echo "stats pass failed ($mode)"
+  i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/$mode/pmc/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 $args > $out/$mode.pmc_p$i.log 2>&1 || echo "pmc pass $i failed ($mode)"
+  done
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $out/pmc > $out/pmc_summary.txt 2>&1
 python3 - <<PY
-import csv, glob
-rows = []
-for f in glob.glob("$out/stats/*/*kernel_stats.csv"):
-    rows = list(csv.DictReader(open(f)))
-with open("$out/kernel_stats_summary.csv", "w") as o:
-    o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --verify-reads 0\n")
-    o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
-    for r in rows:
-        n = r["Name"].replace("(anonymous namespace)::", "")
-        n = n.split("(")[0][-60:]
-        o.write('"%s",%s,%s,%s,%s\n' % (n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
-print(open("$out/kernel_stats_summary.csv").read())
+import csv, glob, json, collections, os
+out = "$out"
+res = {}
+for mode in ("hpc", "regular"):
+    # kernel stats
+    rows = []
+    for f in glob.glob(out + "/%s/stats/*/*kernel_stats.csv" % mode):
+        rows = list(csv.DictReader(open(f)))
+    with open(out + "/%s_kernel_stats.csv" % mode, "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --mode %s --no-other-mode --no-cpu-baseline --verify-reads 0\n" % mode)
+        o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+        for r in rows:
+            n = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
+            o.write('"%s",%s,%s,%s,%s\n' % (n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
+    # counters per kernel, averaged per launch
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(out + "/%s/pmc/p*/*/*counter_collection.csv" % mode):
+        for r in csv.DictReader(open(f)):
+            n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+            n = n.replace("void s2k::", "").replace("s2k::", "")
+            agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines = []
+    fetch = write = 0.0
+    per_kernel = {}
+    for k in sorted(agg):
+        vals = {c: sum(v) / len(v) for c, v in agg[k].items()}
+        calls_per_step = len(agg[k].get("FETCH_SIZE", [])) / 3.0  # 1 warm-up + 2 steps per profiled run
+        lines.append("== %s  (launches per step %.2f)" % (k, calls_per_step))
+        for c in sorted(vals): lines.append("   %-24s %.6g" % (c, vals[c]))
+        f_kb, w_kb = vals.get("FETCH_SIZE", 0.0), vals.get("WRITE_SIZE", 0.0)
+        per_kernel[k] = {"launches_per_step": calls_per_step, "fetch_size_kb": f_kb, "write_size_kb": w_kb,
+                         "hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024)}
+        fetch += f_kb * calls_per_step; write += w_kb * calls_per_step
+    open(out + "/%s_pmc_summary.txt" % mode, "w").write("\n".join(lines) + "\n")
+    res[mode] = {"mode": mode, "n_bases": 10000000000, "hbm_bytes_per_step": int((2 * fetch + write) * 1024),
+                 "fetch_size_kb_per_step": fetch, "write_size_kb_per_step": write, "kernels": per_kernel,
+                 "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on python3 bench.py --steps 2 --warmup 1 --mode %s --no-other-mode; "
+                           "sum over ALL kernels of one step; FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE exact; collected %s" % (mode, os.popen("date -u +%Y-%m-%dT%H:%MZ").read().strip())}
+    print(mode, "HBM bytes per step", res[mode]["hbm_bytes_per_step"])
+json.dump(res["hpc"], open(out + "/traffic_hpc.json", "w"), indent=1)
+json.dump(res["regular"], open(out + "/traffic_regular.json", "w"), indent=1)
 PY
-cat $out/pmc_summary.txt
-python3 - <<PY
-# HBM traffic of the headline (Hpc) minimizer kernel per launch, corrected as MI355X_MICROARCH.md prescribes:
-# FETCH_SIZE reads exactly half of a wide coalesced read stream on gfx950 -> x2; WRITE_SIZE is exact; unit KB.
-import json, re
-txt = open("$out/pmc_summary.txt").read()
-blk = txt.split("== tile_min<hpc>")[1].split("==")[0]
-f = float(re.search(r"FETCH_SIZE\s+(\S+)", blk).group(1)); w = float(re.search(r"WRITE_SIZE\s+(\S+)", blk).group(1))
-blk2 = txt.split("== tile_min<reg>")[1].split("==")[0] if "== tile_min<reg>" in txt else ""
-out = {"mode": "hpc", "n_bases": 10000000000, "hbm_bytes_per_launch": int((2 * f + w) * 1024), "fetch_size_kb": f, "write_size_kb": w,
-       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on python3 bench.py --steps 2 --warmup 1; FETCH_SIZE x2 (gfx950)"}
-if blk2:
-    f2 = float(re.search(r"FETCH_SIZE\s+(\S+)", blk2).group(1)); w2 = float(re.search(r"WRITE_SIZE\s+(\S+)", blk2).group(1))
-    out["regular_hbm_bytes_per_launch"] = int((2 * f2 + w2) * 1024)
-json.dump(out, open("$out/traffic.json", "w"), indent=1)
-print(out)
-PY
+cat $out/hpc_kernel_stats.csv; cat $out/hpc_pmc_summary.txt | head -60
