@@ -2,7 +2,7 @@
   * the CPU oracle rebuilt with -fsanitize=address,undefined (oracle/Makefile: libs2k_oracle_asan.so) runs the golden-vector
     suite -- the reference's own scalar code reads one byte past its input (src/nthash_hpc.rs:213-215); the
     restatement must not;
-  * the C-ABI library rebuilt with host-side ASan (csrc/Makefile: libs2k_asan.so: argument validation, FASTA/FASTQ parser,
+  * the C-ABI library rebuilt with host-side ASan (csrc/Makefile.asan: libs2k_asan.so: argument validation, FASTA/FASTQ parser,
     pinned-ring copy threads) runs the host-only tests (parser on well-formed and malformed files, exports, layouts).
 Each runs in a child interpreter with the sanitizer runtime preloaded; a report makes the child exit non-zero."""
 import os
@@ -37,7 +37,7 @@ def test_oracle_golden_suite_under_asan_ubsan():
 
 def test_host_side_of_the_library_under_asan():
     csrc = os.path.join(ROOT, "rust-seq2kminmers_amd", "csrc")
-    subprocess.check_call(["make", "-s", "-C", csrc, "-j", "4", "libs2k_asan.so"])
+    subprocess.check_call(["make", "-s", "-C", csrc, "-f", "Makefile.asan", "-j", "4", "libs2k_asan.so"])
     import glob
 
     rts = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
