@@ -62,6 +62,7 @@ constexpr int LISTCAP = 256;                           // hits handled per dense
 constexpr int JOBCAP = 32;                             // queued hash re-derivations per flush
 constexpr int REG_LA = 2;
 constexpr int HPC_LA = 2;                              // seed look-ahead (positions) of the Hpc hash loop: 8 spills there
+constexpr int NBL = 32;                                // read starts of a tile kept in LDS (hb / rs); tiles with more search the read table
 constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
 
 struct HpcLds {
@@ -78,13 +79,15 @@ struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
     uint16_t list[LISTCAP];  // validated hits of the current batch: tile-local hash position (bits 0-13), ascending; bit 15 = hash must be re-derived
     uint16_t jobx[JOBCAP];   // hits whose hash must be re-derived: tile-local position ...
     uint32_t jobslot[JOBCAP];// ... and record slot (relative to the tile's base)
-    int16_t hb[64];          // read starts inside the tile, as hash-space positions (ascending; 0 .. TILE_BASES)
-    uint64_t rs[64];         // rs[i] = read_off[r0 + i]
+    int16_t hb[NBL];         // read starts inside the tile, as hash-space positions (ascending; 0 .. TILE_BASES)
+    uint64_t rs[NBL];        // rs[i] = read_off[r0 + i]
 };
 constexpr int TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c], l-1)};  OUT table at 2048: {rotl(h[c], l), rotr(rc[c], 1)}
 template <bool HPC>
 constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>); }
-static_assert(3 * block_lds_bytes<true>() <= 160 * 1024, "three blocks per CU must fit the 160 KiB LDS");
+// the hardware allocates LDS in granules: 3 x 54 400 B did NOT fit (the third block of every CU queued behind the other two
+// and the persistent grid ran 13 % longer) although the occupancy query said 3
+static_assert(3 * (block_lds_bytes<true>() + 1024) <= 160 * 1024, "three blocks per CU must fit the 160 KiB LDS with allocation slack");
 
 // inclusive scan over the 64 lanes with DPP row shifts / broadcasts (no LDS round trips)
 __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -598,7 +601,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
     }
     const uint64_t tile_end = t0 + tile_len;
     uint32_t nb = 0;                  // internal boundaries (reads r0+1 .. r0+nb start inside the tile)
-    const bool many = (r1 - r0) > 62; // more read starts than the LDS lists hold: generic per-hit lookups
+    const bool many = (r1 - r0) > (uint32_t)(NBL - 2); // more read starts than the LDS lists hold: generic per-hit lookups
     if (lane == 0) S.rs[0] = rs0;
     {
         uint64_t bpos = bpos0; // read_off[r0 + 1 + lane], fetched ahead; later chunks are loaded here (rare)
@@ -707,7 +710,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 }
                 chunk_prev = ((uint64_t)bcast((uint32_t)(bpos >> 32), 63) << 32) | bcast((uint32_t)bpos, 63);
             }
-            if (!many && internal && c0 + lane < 63) { // remembered for the per-hit read lookup
+            if (!many && internal && c0 + lane < (uint32_t)(NBL - 1)) { // remembered for the per-hit read lookup
                 S.hb[c0 + lane] = (int16_t)HB;
                 S.rs[c0 + lane + 1] = bpos;
             }
@@ -831,7 +834,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
         const uint32_t bn = N - b0 < (uint32_t)LISTCAP ? N - b0 : (uint32_t)LISTCAP;
         auto rounds = [&](auto many_c) {
         constexpr bool MANY = decltype(many_c)::value;
-        constexpr int U = HPC ? 2 : 1; // hits per lane per iteration: Hpc (two waves per SIMD, 256 VGPRs) overlaps the LDS round trips of two back-maps
+        constexpr int U = 1; // hits per lane per iteration (two overlapped back-maps cost ~25 VGPRs: three waves per SIMD matter more)
         for (uint32_t k0 = 0; k0 < bn; k0 += 64 * U) {
             uint32_t kk[U], x[U], rid[U];
             bool act[U], need_re[U];
@@ -900,7 +903,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                         for (uint32_t i = 0; i < nb; i++) c += (S.hb[i] <= (int32_t)x[u]); // wave-uniform trip count, LDS broadcast
                         rid[u] = r0 + c;
                         rstart = S.rs[c];
-                    } else { // > 62 reads start in this tile: search the read table itself
+                    } else { // > NBL - 2 reads start in this tile: search the read table itself
                         uint32_t lo = r0, hi = r1;
                         while (lo < hi) {
                             uint32_t mid = lo + (hi - lo + 1) / 2;
@@ -934,7 +937,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
             }
         }
         };
-        // > 62 reads starting in one tile take the variant that searches the read table itself; keeping it a
+        // > NBL - 2 reads starting in one tile take the variant that searches the read table itself; keeping it a
         // separate instantiation keeps its global loads out of the common loop
         if (many) rounds(std::true_type{});
         else rounds(std::false_type{});
@@ -949,7 +952,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
 // read-table entries of the current tile are fetched before they are needed, so no global-load latency
 // sits on the critical path except in the first iteration.
 template <int L, bool HPC>
-__global__ __launch_bounds__(64 * TW, HPC ? 2 : S2K_WAVES_PER_SIMD) void tile_minimizer_kernel(
+__global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
     uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
     uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts) {
@@ -1164,6 +1167,11 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
         S2K_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         int occ = 0;
         S2K_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64 * TW, lds));
+        // The occupancy query ignores the granule LDS is allocated in: it answered 3 for 3 x 54 400 B of a 163 840 B LDS, the
+        // hardware kept two blocks per CU resident and the third queued behind them (+13 % kernel time).  Trust it only up to
+        // what fits with every block rounded up to 2 KiB.
+        const int fit = (int)((size_t)prop.sharedMemPerMultiprocessor / (((size_t)lds + 2047) & ~(size_t)2047));
+        if (fit >= 1 && occ > fit) occ = fit;
         per_cu_d[dev] = occ < 1 ? 1 : occ;
 #ifdef S2K_DEBUG_KNOBS // `make KNOBS=1` / `make PROFILE=1` builds only (tools/*.sh): occupancy experiments
         if (const char *e = getenv("S2K_DEBUG_BLOCKS_PER_CU")) per_cu_d[dev] = atoi(e) > 0 ? atoi(e) : per_cu_d[dev];
