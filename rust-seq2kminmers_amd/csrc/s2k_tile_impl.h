@@ -60,7 +60,7 @@ constexpr int NPC = TILE_T / CAPP;                     // 9 capture pieces per l
 constexpr int MAX_L_TILED = 64;
 constexpr int LISTCAP = 256;                           // hits handled per dense batch
 constexpr int JOBCAP = 32;                             // queued hash re-derivations per flush
-constexpr int REG_LA = 2;
+constexpr int REG_LA = 1;
 constexpr int HPC_LA = 2;                              // seed look-ahead (positions) of the Hpc hash loop: 8 spills there
 constexpr int NBL = 32;                                // read starts of a tile kept in LDS (hb / rs); tiles with more search the read table
 constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
