@@ -768,38 +768,56 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
         if ((uint32_t)lane <= nb && mine) atomicAdd(&mn_cnt[r0 + lane], mine);
     }
     uint32_t njobs = 0;
+    // Re-derivation of queued hashes (closed form src/nthash_hpc.rs:144,168): FOUR lanes per job, each takes a quarter of the l
+    // bases (two LDS round trips per pass of 16 jobs instead of eight per lane), partial hashes are XOR-ed across the quad by DPP.
     auto flush_jobs = [&]() {
         wave_sync();
-        if ((uint32_t)lane < njobs) {
-            const uint8_t *q = D + S.jobx[lane];
+        const uint32_t part = (uint32_t)lane & 3u;
+        const uint32_t per = (l + 3u) >> 2;          // bases per lane
+        const uint32_t i0 = per * part;              // first base of this lane
+        for (uint32_t j0 = 0; j0 < njobs; j0 += 16) { // wave-uniform
+            const uint32_t job = j0 + ((uint32_t)lane >> 2);
+            const bool act = job < njobs;
+            const uint8_t *q = D + (act ? S.jobx[job] : 0) + i0;
             uint32_t f = 0, r = 0;
-            if constexpr (L > 0) { // groups of 8 bases: byte reads, then seed reads, then the rotate-xors (bounded register use)
+            if constexpr (L > 0) {
+                constexpr uint32_t PER = (L + 3) / 4;
 #pragma unroll
-                for (int i0 = 0; i0 < L; i0 += 8) {
-                    uint32_t by[8];
-                    uint2 ti[8];
+                for (uint32_t h0 = 0; h0 < PER; h0 += 4) { // groups of four bases: bounded register use
+                    uint32_t by[4];
+                    uint2 ti[4];
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        if (i0 + i < L) by[i] = q[i0 + i];
+                    for (uint32_t ii = 0; ii < 4; ii++)
+                        if (h0 + ii < PER) by[ii] = q[h0 + ii];
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        if (i0 + i < L) ti[i] = tab_in(tab, by[i]); // IN pair = {h[c], rotl(rc[c], l-1)}
+                    for (uint32_t ii = 0; ii < 4; ii++)
+                        if (h0 + ii < PER) ti[ii] = tab_in(tab, by[ii]); // IN pair = {h[c], rotl(rc[c], l-1)}
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        if (i0 + i < L) {
-                            f ^= rotl32(ti[i].x, L - 1 - (i0 + i));
-                            r ^= rotr32(ti[i].y, L - 1 - (i0 + i));
+                    for (uint32_t ii = 0; ii < 4; ii++)
+                        if (h0 + ii < PER) {
+                            const uint32_t i = i0 + h0 + ii, rot = (uint32_t)L - 1u - i;
+                            const bool valid = 3 * PER + h0 + ii < (uint32_t)L || i < (uint32_t)L; // only the last quarter can run past l
+                            f ^= valid ? rotl32(ti[ii].x, rot) : 0u;
+                            r ^= valid ? rotr32(ti[ii].y, rot) : 0u;
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
-                for (uint32_t i = 0; i < l; i++) {
-                    const uint2 ti = tab_in(tab, q[i]);
-                    f ^= rotl32(ti.x, l - 1 - i);
-                    r ^= rotr32(ti.y, l - 1 - i);
+                for (uint32_t ii = 0; ii < per; ii++) {
+                    const uint32_t i = i0 + ii;
+                    if (i < l) {
+                        const uint2 ti = tab_in(tab, q[ii]);
+                        f ^= rotl32(ti.x, l - 1 - i);
+                        r ^= rotr32(ti.y, l - 1 - i);
+                    }
                 }
             }
-            rec.hash[base + S.jobslot[lane]] = f < r ? f : r;
+            // XOR over the four lanes of the quad: quad_perm [1,0,3,2] then [2,3,0,1]
+            f ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0xB1, 0xf, 0xf, false);
+            r ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0xB1, 0xf, 0xf, false);
+            f ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x4E, 0xf, 0xf, false);
+            r ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x4E, 0xf, 0xf, false);
+            if (act && part == 0) rec.hash[base + S.jobslot[job]] = f < r ? f : r;
         }
         njobs = 0;
         wave_sync();
