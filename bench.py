@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--verify-reads", type=int, default=300)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: map every rank to GPU 0")
+    ap.add_argument("--count", action="store_true", help="also time the downstream k-min-mer count (hash table in HBM; N > 1: all-to-all by hash prefix)")
     ap.add_argument("--dump-shard", default=None, help="(tests) write this rank's outputs to <path>.rank<r>.npz")
     return ap.parse_args()
 
@@ -280,6 +281,27 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         balance = round(float(tmax.item()) / (tot_bases / world), 4)  # largest shard / mean shard, in bases
 
+    # ---- downstream of the path, outside the headline: distinct k-min-mer hashes over all ranks -------------
+    count_line = None
+    if args.count:
+        ops = sharding.EngineCountOps(eng, dev)
+        keys = outs["hash"][: counts["n_kminmers"]]
+        sharding.count_kminmers(keys, ops, dist, collectives_on_device=(args.backend == "nccl"))  # warm-up (table allocation)
+        barrier()
+        tc0 = time.perf_counter()
+        cr = sharding.count_kminmers(keys, ops, dist, collectives_on_device=(args.backend == "nccl"))
+        barrier()
+        tc = time.perf_counter() - tc0
+        if dist is not None:
+            tt = torch.tensor([tc], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tc = float(tt.item())
+        # bytes: every key read once for the partition (N > 1: written and read once more, 8 B over xGMI), once for the insert,
+        # plus one 12-byte table slot touched per insert and the 12-byte slots swept by the compaction (>= 2 slots per key)
+        count_line = {"n_keys": cr["n_keys"], "n_distinct": cr["n_distinct"], "ms": round(tc * 1e3, 3),
+                      "keys_per_s": round(cr["n_keys"] / tc / 1e9, 3), "unit": "G keys/s",
+                      "exchange": None if world == 1 else "all_to_all_single by hash prefix (%s), 8 B per key" % args.backend}
+
     # ---- roofline (rank 0's launch): SURVEY.md 8d  B = N_bases*1 + N_kminmers*17 + 16*(N_reads+1) --------------------
     # each input byte once, each k-min-mer once (u64 hash + u32 start + u32 end + u8 rev), both offset tables;
     # divided by the HIP-event time of ALL kernels of the step (tile index, minimizer kernel, scans, k-min-mer kernel).
@@ -366,7 +388,7 @@ def main():
                 "largest_shard_over_mean": balance}, **shard_info),
             "counts": {"bases": tot_bases, "minimizers": tot_min, "kminmers": tot_km, "xor_hash_rank0": counts["xor_hash"]},
             "verified_vs_oracle": verified,
-            "other_mode": other_line,
+            "other_mode": other_line, "downstream_count": count_line,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
