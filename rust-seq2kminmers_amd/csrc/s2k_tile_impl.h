@@ -338,7 +338,9 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
         }                                                                                \
     } while (0)
 #else
+#ifndef S2K_WAVES_PER_SIMD
 #define S2K_WAVES_PER_SIMD 3
+#endif
 #define S2K_STAMP(i) do { (void)ph; (void)stamp; } while (0)
 #endif
 
