@@ -324,6 +324,13 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
     else hash_loop_dynamic(D, tab, bound, lane, l, np, caps, raw);
 }
 
+// Dynamic dealing of tiles (one atomicAdd on a device-wide cursor per tile, taken two iterations ahead) was measured and
+// lost: 1.085 M atomics on ONE address from eight XCDs are serialised at ~12 ns each, the kernel took 13.2 ms in both modes
+// (static dealing: 8.2 / 5.9 ms).  Kept as a compile-time experiment (-DS2K_DYNAMIC_TILES=1); tiles are dealt round-robin.
+#ifndef S2K_DYNAMIC_TILES
+#define S2K_DYNAMIC_TILES 0
+#endif
+
 // Phase stamps (cycles per phase, kept in registers and flushed once per tile to one of 64 shards) exist only in
 // builds with -DS2K_PROFILE (tools/phases.sh): the 16 accumulators cost 32 VGPRs that production kernels need.
 #ifdef S2K_PROFILE
@@ -341,6 +348,7 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
 #ifndef S2K_WAVES_PER_SIMD
 #define S2K_WAVES_PER_SIMD 3
 #endif
+
 #define S2K_STAMP(i) do { (void)ph; (void)stamp; } while (0)
 #endif
 
@@ -1033,13 +1041,18 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         prefetch(t);
         have_pre = true;
     }
+    // tn / tnn: the next two tiles of this wave (t + n_waves, t + 2 n_waves; with S2K_DYNAMIC_TILES every tile after the first
+    // three comes from the cursor pool_cursor[1], zeroed by the host before the launch)
+    uint64_t tn = t + n_waves, tnn = t + 2 * n_waves; // >= n_tiles: none
     uint32_t r0n = 0, r1n = 0;
-    if (t + n_waves < n_tiles) {
-        r0n = tile_read0[t + n_waves];
-        r1n = tile_read0[t + n_waves + 1];
+    if (tn < n_tiles) {
+        r0n = tile_read0[tn];
+        r1n = tile_read0[tn + 1];
     }
 
-    for (; t < n_tiles; t += n_waves) {
+    for (; t < n_tiles;) {
+        uint32_t took = 0; // the tile after tnn
+        if (S2K_DYNAMIC_TILES && lane == 0 && tnn < n_tiles) took = (uint32_t)atomicAdd((unsigned long long *)&pool_cursor[1], 1ull);
         const uint64_t t0 = t * (uint64_t)TILE_BASES;
         l16_tile = 16 * lane;
         // Regular: opaque, so that the staging / prefetch addresses are formed per tile instead of living in 20 hoisted
@@ -1108,15 +1121,15 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         uint32_t r0nn = 0, r1nn = 0;
         auto issue_next = [&]() {
             have_pre = false;
-            if (t + n_waves < n_tiles) {
-                if (is_full(t + n_waves)) {
-                    prefetch(t + n_waves);
+            if (tn < n_tiles) {
+                if (is_full(tn)) {
+                    prefetch(tn);
                     have_pre = true;
                 }
                 read_entries(r0n, bposn, rs0n);
-                if (t + 2 * n_waves < n_tiles) {
-                    r0nn = tile_read0[t + 2 * n_waves];
-                    r1nn = tile_read0[t + 2 * n_waves + 1];
+                if (tnn < n_tiles) {
+                    r0nn = tile_read0[tnn];
+                    r1nn = tile_read0[tnn + 1];
                 }
             }
             if (!have_pre) { // tell the compiler the staged registers are dead (they would stay live across the whole loop body)
@@ -1157,6 +1170,10 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         }
         wave_sync(); // LDS of this wave is reused by the next tile
         r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; // rotate the pipeline
+        t = tn;
+        tn = tnn;
+        if (S2K_DYNAMIC_TILES) tnn = tnn < n_tiles ? 3 * n_waves + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)took) : tnn;
+        else tnn += n_waves;
         S2K_STAMP(6); // tail
     }
 #ifdef S2K_PROFILE
