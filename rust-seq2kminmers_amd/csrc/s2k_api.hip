@@ -10,6 +10,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <chrono>
+#include <memory>
+#include <mutex>
+#include <sys/mman.h>
 #include <vector>
 
 using namespace s2k;
@@ -18,14 +22,76 @@ static_assert(offsetof(Counts, path) == offsetof(s2k_counts, path), "Counts must
 
 namespace {
 
-struct HostOwner { // backing store of an s2k_result: plain malloc (no zero fill -- the arrays are overwritten whole)
+// Host memory of s2k_result arrays.  A fresh malloc of a gigabyte is a gigabyte of page faults in the copy threads that
+// drain the D2H ring (measured: 1.3 GB of results took 104 ms to land instead of 35), so blocks given back by
+// s2k_result_free are kept by the context that made them and reused by its next call; new blocks are 2 MiB-aligned and
+// advised to transparent huge pages.  The pool outlives the context while results still refer to it.
+struct HostPool {
+    struct Blk {
+        void *p;
+        size_t cap;
+    };
+    std::mutex mu;
+    std::vector<Blk> idle;
+    static constexpr size_t kKeep = 18; // two calls' worth of arrays
+    void *get(size_t bytes, size_t *cap) {
+        if (bytes == 0) bytes = 1;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); i++) // smallest block that fits and is not grossly oversized
+                if (idle[i].cap >= bytes && idle[i].cap / 4 <= bytes + (1u << 20) && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+            if (best != idle.size()) {
+                Blk b = idle[best];
+                idle.erase(idle.begin() + (long)best);
+                *cap = b.cap;
+                return b.p;
+            }
+        }
+        void *q = nullptr;
+        size_t want = bytes;
+        if (bytes >= (4u << 20)) {
+            want = (bytes + bytes / 16 + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+            if (posix_memalign(&q, 2u << 20, want) != 0) q = nullptr;
+            if (q) (void)madvise(q, want, MADV_HUGEPAGE);
+        } else {
+            q = malloc(want);
+        }
+        *cap = q ? want : 0;
+        return q;
+    }
+    void put(void *q, size_t cap) {
+        if (!q) return;
+        void *drop = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            idle.push_back(Blk{q, cap});
+            if (idle.size() > kKeep) { // drop the smallest
+                size_t m = 0;
+                for (size_t i = 1; i < idle.size(); i++)
+                    if (idle[i].cap < idle[m].cap) m = i;
+                drop = idle[m].p;
+                idle.erase(idle.begin() + (long)m);
+            }
+        }
+        free(drop);
+    }
+    ~HostPool() {
+        for (Blk &b : idle) free(b.p);
+    }
+};
+
+struct HostOwner { // backing store of one s2k_result (no zero fill -- the arrays are overwritten whole)
+    std::shared_ptr<HostPool> pool;
     void *p[9] = {};
+    size_t cap[9] = {};
+    explicit HostOwner(std::shared_ptr<HostPool> hp) : pool(std::move(hp)) {}
     template <typename T> T *take(int slot, uint64_t n) {
-        p[slot] = malloc((n ? n : 1) * sizeof(T));
+        p[slot] = pool->get((size_t)n * sizeof(T), &cap[slot]);
         return (T *)p[slot];
     }
     ~HostOwner() {
-        for (void *q : p) free(q);
+        for (int i = 0; i < 9; i++) pool->put(p[i], cap[i]);
     }
 };
 
@@ -96,6 +162,7 @@ struct s2k_ctx {
     s2k_status pending_status = S2K_OK;
     std::string err;
     s2k::HostStager stager; // pinned ring + copy threads of the host-buffer entry points
+    std::shared_ptr<HostPool> host_pool = std::make_shared<HostPool>(); // result arrays of s2k_extract
 };
 
 // context internals for the other translation units of the library (declared in s2k_hostcopy.h)
@@ -570,6 +637,14 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
     if (n_bases && !bases) return fail(ctx, S2K_ERR_INVALID_ARG, "bases is NULL");
     S2K_TRY(hipSetDevice(ctx->device), "set device");
     if (ctx->pending) (void)finish(ctx, nullptr);
+#ifdef S2K_DEBUG_KNOBS // phase times of this call on stderr (tools/pcie_rate.py with a KNOBS build)
+    const bool trace = getenv("S2K_TRACE_EXTRACT") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tq[6] = {now(), 0, 0, 0, 0, 0};
+#define S2K_TQ(i) do { if (trace) tq[i] = now(); } while (0)
+#else
+#define S2K_TQ(i) do { } while (0)
+#endif
 
     // inputs -> HBM (+ 64 B of slack so vector loads of the last tile stay inside the allocation)
     S2K_TRY(ctx->in_bases.ensure(n_bases + 256), "input allocation");
@@ -581,6 +656,7 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
     else S2K_TRY(ctx->stager.h2d_packed(ctx->in_bases.p, bases + first, n_bases, ctx->stream), "H2D bases (2-bit packed)");
     S2K_TRY(hipMemcpyAsync(ctx->in_off.p, off.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream), "H2D offsets");
     S2K_TRY(hipStreamSynchronize(ctx->stream), "H2D sync");
+    S2K_TQ(1);
 
     const bool want_mn = params->flags & S2K_FLAG_WANT_MINIMIZERS;
     uint64_t cap = pool_estimate(n_bases, n_reads, params->density, sem.hpc);
@@ -620,7 +696,8 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
         break;
     }
 
-    HostOwner *ow = new (std::nothrow) HostOwner();
+    S2K_TQ(2);
+    HostOwner *ow = new (std::nothrow) HostOwner(ctx->host_pool);
     if (!ow) return fail(ctx, S2K_ERR_NOMEM, "host result allocation");
     const uint64_t nk = cnt.n_kminmers, nm = cnt.n_minimizers;
     res->km_off = ow->take<uint64_t>(0, n_reads + 1);
@@ -641,6 +718,7 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
         memset(res, 0, sizeof *res);
         return fail(ctx, S2K_ERR_NOMEM, "host result allocation");
     }
+    S2K_TQ(3);
     hipStream_t s = ctx->stream;
     s2k::HostStager &hs = ctx->stager;
     hipError_t e = hs.d2h(res->km_off, o.km_off, (n_reads + 1) * 8, s);
@@ -665,6 +743,13 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
     res->n_minimizers = want_mn ? nm : 0;
     res->counts = cnt;
     res->_owner = ow;
+#ifdef S2K_DEBUG_KNOBS
+    if (trace) {
+        tq[4] = now();
+        fprintf(stderr, "s2k_extract: H2D %.1f ms, kernels %.1f, host alloc %.1f, D2H %.1f, total %.1f ms (%.2f Gbp)\n", tq[1] - tq[0],
+                tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[4] - tq[0], n_bases * 1e-9);
+    }
+#endif
     return S2K_OK;
 }
 
