@@ -122,6 +122,10 @@ s2k_ctx *s2k_create(int device, s2k_status *status);
 void s2k_destroy(s2k_ctx *ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
 s2k_status s2k_set_stream(s2k_ctx *ctx, void *hip_stream);
+/* s2k_extract cuts a call into sub-batches of whole reads of about `bases` bases each (default 2^29; 0 restores it) and
+ * pipelines them: H2D of one, kernels of the previous, D2H of the one before run side by side.  Results do not depend
+ * on it. */
+s2k_status s2k_set_host_batch(s2k_ctx *ctx, uint64_t bases);
 const char *s2k_strerror(s2k_status st);
 const char *s2k_last_error(const s2k_ctx *ctx);
 

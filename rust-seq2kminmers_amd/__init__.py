@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libs2k.so")
 
 ABI_SYMBOLS = [
-    "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_strerror",
+    "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_set_host_batch", "s2k_strerror",
     "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
     "s2k_hpc_device", "s2k_hpc_device_ex", "s2k_count_device", "s2k_partition_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
 ]
@@ -100,6 +100,8 @@ def load_library(path=None):
     L.s2k_destroy.argtypes = [C.c_void_p]
     L.s2k_destroy.restype = None
     L.s2k_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.s2k_set_host_batch.argtypes = [C.c_void_p, C.c_uint64]
+    L.s2k_set_host_batch.restype = C.c_int
     L.s2k_strerror.restype = C.c_char_p
     L.s2k_strerror.argtypes = [C.c_int]
     L.s2k_last_error.restype = C.c_char_p
@@ -186,6 +188,10 @@ class Engine:
 
     def set_stream(self, hip_stream_handle):
         self._check(self.lib.s2k_set_stream(self.ctx, C.c_void_p(int(hip_stream_handle))))
+
+    def set_host_batch(self, bases):
+        """Bases per sub-batch of `extract` (host buffers): H2D / kernels / D2H of consecutive sub-batches overlap."""
+        self._check(self.lib.s2k_set_host_batch(self.ctx, int(bases)))
 
     def enable_timing(self, on=True):
         self._check(self.lib.s2k_enable_timing(self.ctx, 1 if on else 0))

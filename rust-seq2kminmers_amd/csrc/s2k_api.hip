@@ -10,7 +10,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <thread>
 #include <memory>
 #include <mutex>
 #include <sys/mman.h>
@@ -150,6 +154,9 @@ struct s2k_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevBuf ws, in_bases, in_off, outbuf, realign; // realign: aligned copy of a caller's misaligned device stream
+    DevBuf in_bases2, in_off2, outbuf2;           // second set: s2k_extract double-buffers its sub-batches
+    hipStream_t s_in = nullptr, s_out = nullptr;  // s2k_extract: H2D of the next / D2H of the previous sub-batch
+    uint64_t host_batch = 1ull << 29;             // bases per sub-batch of s2k_extract (s2k_set_host_batch)
     Counts *d_counts = nullptr;
     Counts *h_counts = nullptr; // pinned
     uint64_t *d_xor = nullptr;
@@ -162,6 +169,7 @@ struct s2k_ctx {
     s2k_status pending_status = S2K_OK;
     std::string err;
     s2k::HostStager stager; // pinned ring + copy threads of the host-buffer entry points
+    s2k::HostStager stager_out; // ... of the result drain, which runs beside the next sub-batch's H2D
     std::shared_ptr<HostPool> host_pool = std::make_shared<HostPool>(); // result arrays of s2k_extract
 };
 
@@ -513,6 +521,11 @@ void s2k_destroy(s2k_ctx *ctx) {
     ctx->realign.release();
     ctx->in_off.release();
     ctx->outbuf.release();
+    ctx->in_bases2.release();
+    ctx->in_off2.release();
+    ctx->outbuf2.release();
+    if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
+    if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
     if (ctx->d_xor) (void)hipFree(ctx->d_xor);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -620,6 +633,175 @@ s2k_status s2k_sync(s2k_ctx *ctx, s2k_counts *counts) {
     return finish(ctx, counts);
 }
 
+// ---- s2k_extract: host buffers in, host SoA out ----------------------------------------------------------------------
+// A call is cut into sub-batches of whole reads (~0.5 Gbp each) and pipelined: while the kernels of sub-batch b run, the
+// copy threads already pack and send b+1 (own stream, own pinned ring) and a second host thread drains the results of
+// b-1 into the result arrays (third stream, second ring).  PCIe is full duplex: the call then costs max(H2D, D2H) instead
+// of their sum.  Everything a sub-batch yields is read-relative, so the pieces concatenate; only km_off / mn_off need
+// the running totals added.
+namespace {
+
+s2k_status carve_out(s2k_ctx *ctx, DevBuf &buf, uint64_t n_reads, uint64_t cap, bool want_mn, s2k_device_out *o) {
+    Arena a{nullptr, 0, 0};
+    for (int pass = 0; pass < 2; pass++) { // km <= minimizers <= cap, so one capacity serves every output array
+        a.off = 0;
+        memset(o, 0, sizeof *o);
+        o->km_capacity = cap;
+        o->km_off = a.take<uint64_t>(n_reads + 1);
+        o->hash = a.take<uint64_t>(cap);
+        o->start = a.take<uint32_t>(cap);
+        o->end = a.take<uint32_t>(cap);
+        o->rev = a.take<uint8_t>(cap);
+        if (want_mn) {
+            o->mn_capacity = cap;
+            o->mn_off = a.take<uint64_t>(n_reads + 1);
+            o->mn_j = a.take<uint32_t>(cap);
+            o->mn_jend = a.take<uint32_t>(cap);
+            o->mn_hash = a.take<uint32_t>(cap);
+        }
+        if (pass == 0) {
+            S2K_TRY(buf.ensure(a.off + 256), "output allocation");
+            a.base = (char *)buf.p;
+        }
+    }
+    return S2K_OK;
+}
+
+struct SubBatch { // one finished sub-batch waiting for its results to be drained
+    int slot = 0;
+    uint64_t r_lo = 0, n_reads = 0, n_bases = 0;
+    s2k_counts cnt{};
+    s2k_device_out o{};
+};
+
+struct Drain { // the s2k_result under construction and the thread that fills it
+    s2k_ctx *ctx;
+    HostOwner *ow;
+    s2k_result *res;
+    bool want_mn;
+    uint64_t cap_k = 0, cap_m = 0, used_k = 0, used_m = 0; // elements
+    std::atomic<hipError_t> err{hipSuccess};
+    std::atomic<bool> nomem{false};
+    // hand-over
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<SubBatch> queue;
+    bool closed = false;
+    bool slot_busy[2] = {false, false};
+
+    bool grow(int slot, size_t es, uint64_t used, uint64_t want) {
+        size_t ncap = 0;
+        void *q = ow->pool->get((size_t)want * es, &ncap);
+        if (!q) return false;
+        if (used) memcpy(q, ow->p[slot], (size_t)used * es);
+        ow->pool->put(ow->p[slot], ow->cap[slot]);
+        ow->p[slot] = q;
+        ow->cap[slot] = ncap;
+        return true;
+    }
+    bool ensure(uint64_t nk, uint64_t nm) { // the estimate of the whole call was too small (rare): grow, keep what is there
+        if (nk > cap_k) {
+            const uint64_t w = nk + nk / 8 + 4096;
+            if (!grow(1, 8, used_k, w) || !grow(2, 4, used_k, w) || !grow(3, 4, used_k, w) || !grow(4, 1, used_k, w)) return false;
+            cap_k = w;
+            res->hash = (uint64_t *)ow->p[1];
+            res->start = (uint32_t *)ow->p[2];
+            res->end = (uint32_t *)ow->p[3];
+            res->rev = (uint8_t *)ow->p[4];
+        }
+        if (want_mn && nm > cap_m) {
+            const uint64_t w = nm + nm / 8 + 4096;
+            if (!grow(6, 4, used_m, w) || !grow(7, 4, used_m, w) || !grow(8, 4, used_m, w)) return false;
+            cap_m = w;
+            res->mn_j = (uint32_t *)ow->p[6];
+            res->mn_jend = (uint32_t *)ow->p[7];
+            res->mn_hash = (uint32_t *)ow->p[8];
+        }
+        return true;
+    }
+    void drain(const SubBatch &b) { // D2H of one sub-batch, appended to the result
+        if (err != hipSuccess || nomem) return;
+        const uint64_t nk = b.cnt.n_kminmers, nm = b.cnt.n_minimizers;
+        if (!ensure(used_k + nk, used_m + nm)) {
+            nomem = true;
+            return;
+        }
+        hipStream_t s = ctx->s_out;
+        s2k::HostStager &hs = ctx->stager_out;
+        hipError_t e = hs.d2h(res->km_off + b.r_lo, b.o.km_off, (b.n_reads + 1) * 8, s);
+        if (e == hipSuccess) e = hs.d2h(res->hash + used_k, b.o.hash, nk * 8, s);
+        if (e == hipSuccess) e = hs.d2h(res->start + used_k, b.o.start, nk * 4, s);
+        if (e == hipSuccess) e = hs.d2h(res->end + used_k, b.o.end, nk * 4, s);
+        if (e == hipSuccess) e = hs.d2h(res->rev + used_k, b.o.rev, nk, s);
+        if (want_mn) {
+            if (e == hipSuccess) e = hs.d2h(res->mn_off + b.r_lo, b.o.mn_off, (b.n_reads + 1) * 8, s);
+            if (e == hipSuccess) e = hs.d2h(res->mn_j + used_m, b.o.mn_j, nm * 4, s);
+            if (e == hipSuccess) e = hs.d2h(res->mn_jend + used_m, b.o.mn_jend, nm * 4, s);
+            if (e == hipSuccess) e = hs.d2h(res->mn_hash + used_m, b.o.mn_hash, nm * 4, s);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            err = e;
+            return;
+        }
+        if (used_k)
+            for (uint64_t r = 0; r <= b.n_reads; r++) res->km_off[b.r_lo + r] += used_k;
+        if (want_mn && used_m)
+            for (uint64_t r = 0; r <= b.n_reads; r++) res->mn_off[b.r_lo + r] += used_m;
+        used_k += nk;
+        used_m += nm;
+    }
+    void run() { // consumer thread
+        (void)hipSetDevice(ctx->device);
+        for (;;) {
+            SubBatch b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return closed || !queue.empty(); });
+                if (queue.empty()) return;
+                b = queue.front();
+                queue.erase(queue.begin());
+            }
+            drain(b);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                slot_busy[b.slot] = false;
+            }
+            cv.notify_all();
+        }
+    }
+    void push(const SubBatch &b) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            queue.push_back(b);
+        }
+        cv.notify_all();
+    }
+    void wait_slot_free(int slot) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !slot_busy[slot]; });
+    }
+    void mark_busy(int slot) {
+        std::lock_guard<std::mutex> lk(mu);
+        slot_busy[slot] = true;
+    }
+    void close() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            closed = true;
+        }
+        cv.notify_all();
+    }
+};
+
+} // namespace
+
+s2k_status s2k_set_host_batch(s2k_ctx *ctx, uint64_t bases) {
+    if (!ctx) return S2K_ERR_INVALID_ARG;
+    ctx->host_batch = bases ? bases : (1ull << 29);
+    return S2K_OK;
+}
+
 s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
                        const s2k_params *params, s2k_result *res) {
     if (!ctx || !res) return S2K_ERR_INVALID_ARG;
@@ -637,118 +819,161 @@ s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_
     if (n_bases && !bases) return fail(ctx, S2K_ERR_INVALID_ARG, "bases is NULL");
     S2K_TRY(hipSetDevice(ctx->device), "set device");
     if (ctx->pending) (void)finish(ctx, nullptr);
-#ifdef S2K_DEBUG_KNOBS // phase times of this call on stderr (tools/pcie_rate.py with a KNOBS build)
+#ifdef S2K_DEBUG_KNOBS // wall time of this call on stderr (tools/pcie_trace.sh with a KNOBS build)
     const bool trace = getenv("S2K_TRACE_EXTRACT") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double tq[6] = {now(), 0, 0, 0, 0, 0};
-#define S2K_TQ(i) do { if (trace) tq[i] = now(); } while (0)
-#else
-#define S2K_TQ(i) do { } while (0)
+    const auto t_begin = std::chrono::steady_clock::now();
 #endif
 
-    // inputs -> HBM (+ 64 B of slack so vector loads of the last tile stay inside the allocation)
-    S2K_TRY(ctx->in_bases.ensure(n_bases + 256), "input allocation");
-    S2K_TRY(ctx->in_off.ensure((n_reads + 1) * sizeof(uint64_t)), "input allocation");
-    std::vector<uint64_t> off(n_reads + 1);
-    for (uint64_t r = 0; r <= n_reads; r++) off[r] = read_off[r] - first;
-    // bases cross PCIe packed to 2 bits (exact: every non-ACGT byte travels in a side list), unless the caller opts out
-    if (params->flags & S2K_FLAG_NO_PACK2) S2K_TRY(ctx->stager.h2d(ctx->in_bases.p, bases + first, n_bases, ctx->stream), "H2D bases");
-    else S2K_TRY(ctx->stager.h2d_packed(ctx->in_bases.p, bases + first, n_bases, ctx->stream), "H2D bases (2-bit packed)");
-    S2K_TRY(hipMemcpyAsync(ctx->in_off.p, off.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream), "H2D offsets");
-    S2K_TRY(hipStreamSynchronize(ctx->stream), "H2D sync");
-    S2K_TQ(1);
-
-    const bool want_mn = params->flags & S2K_FLAG_WANT_MINIMIZERS;
-    uint64_t cap = pool_estimate(n_bases, n_reads, params->density, sem.hpc);
-    s2k_counts cnt;
-    s2k_device_out o;
-    for (int attempt = 0;; attempt++) {
-        // km <= minimizers <= cap, so one capacity serves every output array
-        Arena a{nullptr, 0, 0};
-        for (int pass = 0; pass < 2; pass++) {
-            a.off = 0;
-            memset(&o, 0, sizeof o);
-            o.km_capacity = cap;
-            o.km_off = a.take<uint64_t>(n_reads + 1);
-            o.hash = a.take<uint64_t>(cap);
-            o.start = a.take<uint32_t>(cap);
-            o.end = a.take<uint32_t>(cap);
-            o.rev = a.take<uint8_t>(cap);
-            if (want_mn) {
-                o.mn_capacity = cap;
-                o.mn_off = a.take<uint64_t>(n_reads + 1);
-                o.mn_j = a.take<uint32_t>(cap);
-                o.mn_jend = a.take<uint32_t>(cap);
-                o.mn_hash = a.take<uint32_t>(cap);
-            }
-            if (pass == 0) {
-                S2K_TRY(ctx->outbuf.ensure(a.off + 256), "output allocation");
-                a.base = (char *)ctx->outbuf.p;
-            }
+    // ---- sub-batches of whole reads, balanced by bases ------------------------------------------------------------
+    std::vector<uint64_t> cut{0};
+    {
+        const uint64_t bb = ctx->host_batch;
+        const uint64_t nb = n_bases < bb + bb / 2 ? 1 : (n_bases + bb / 2) / bb;
+        for (uint64_t b = 1; b < nb; b++) {
+            const uint64_t target = first + (uint64_t)((unsigned __int128)n_bases * b / nb);
+            const uint64_t r = (uint64_t)(std::lower_bound(read_off, read_off + n_reads + 1, target) - read_off);
+            if (r > cut.back() && r < n_reads) cut.push_back(r);
         }
-        st = s2k_extract_device(ctx, (const uint8_t *)ctx->in_bases.p, (const uint64_t *)ctx->in_off.p, n_reads, n_bases,
-                                params, &o, &cnt);
-        if (st == S2K_ERR_CAPACITY && attempt < 3) {
-            cap = (cnt.n_minimizers > cnt.n_kminmers ? cnt.n_minimizers : cnt.n_kminmers) + 4096;
-            continue;
-        }
-        if (st != S2K_OK) return st;
-        break;
+        cut.push_back(n_reads);
     }
+    const size_t B = cut.size() - 1;
+    if (B > 1) {
+        if (!ctx->s_in) S2K_TRY(hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking), "stream create");
+    }
+    if (!ctx->s_out) S2K_TRY(hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking), "stream create");
+    hipStream_t s_in = B > 1 ? ctx->s_in : ctx->stream;
 
-    S2K_TQ(2);
+    // ---- the result arrays, sized by the estimate for the whole call (they grow if it was too small) -----------------
+    const bool want_mn = params->flags & S2K_FLAG_WANT_MINIMIZERS;
     HostOwner *ow = new (std::nothrow) HostOwner(ctx->host_pool);
     if (!ow) return fail(ctx, S2K_ERR_NOMEM, "host result allocation");
-    const uint64_t nk = cnt.n_kminmers, nm = cnt.n_minimizers;
-    res->km_off = ow->take<uint64_t>(0, n_reads + 1);
-    res->hash = ow->take<uint64_t>(1, nk);
-    res->start = ow->take<uint32_t>(2, nk);
-    res->end = ow->take<uint32_t>(3, nk);
-    res->rev = ow->take<uint8_t>(4, nk);
-    if (want_mn) {
-        res->mn_off = ow->take<uint64_t>(5, n_reads + 1);
-        res->mn_j = ow->take<uint32_t>(6, nm);
-        res->mn_jend = ow->take<uint32_t>(7, nm);
-        res->mn_hash = ow->take<uint32_t>(8, nm);
+    Drain dr{ctx, ow, res, want_mn};
+    {
+        // one sub-batch: allocated at the exact size when the counts are known; several: the bound the device arrays use
+        // (pages that are never touched cost nothing)
+        const uint64_t est = B == 1 ? 0 : pool_estimate(n_bases, n_reads, params->density, sem.hpc);
+        res->km_off = ow->take<uint64_t>(0, n_reads + 1);
+        if (want_mn) res->mn_off = ow->take<uint64_t>(5, n_reads + 1);
+        bool ok = res->km_off && (!want_mn || res->mn_off);
+        if (ok && est) {
+            res->hash = ow->take<uint64_t>(1, est);
+            res->start = ow->take<uint32_t>(2, est);
+            res->end = ow->take<uint32_t>(3, est);
+            res->rev = ow->take<uint8_t>(4, est);
+            dr.cap_k = est;
+            ok = res->hash && res->start && res->end && res->rev;
+            if (ok && want_mn) {
+                res->mn_j = ow->take<uint32_t>(6, est);
+                res->mn_jend = ow->take<uint32_t>(7, est);
+                res->mn_hash = ow->take<uint32_t>(8, est);
+                dr.cap_m = est;
+                ok = res->mn_j && res->mn_jend && res->mn_hash;
+            }
+        }
+        if (!ok) {
+            delete ow;
+            memset(res, 0, sizeof *res);
+            return fail(ctx, S2K_ERR_NOMEM, "host result allocation");
+        }
     }
-    bool mem_ok = true;
-    for (int i = 0; i < (want_mn ? 9 : 5); i++) mem_ok = mem_ok && ow->p[i];
-    if (!mem_ok) {
+    std::thread consumer;
+    if (B > 1) consumer = std::thread([&dr] { dr.run(); });
+    auto bail = [&](s2k_status code) { // leave nothing behind: consumer joined, result freed
+        if (consumer.joinable()) {
+            dr.close();
+            consumer.join();
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->pending = false;
         delete ow;
         memset(res, 0, sizeof *res);
-        return fail(ctx, S2K_ERR_NOMEM, "host result allocation");
+        return code;
+    };
+
+    DevBuf *in_b[2] = {&ctx->in_bases, &ctx->in_bases2}, *in_o[2] = {&ctx->in_off, &ctx->in_off2};
+    DevBuf *out_b[2] = {&ctx->outbuf, &ctx->outbuf2};
+    s2k_counts total{};
+    total.hash_bound = bound;
+    std::vector<uint64_t> off;
+    SubBatch prev;
+    bool have_prev = false;
+    // finishes sub-batch `prev` (its kernels ran while the next one was being sent) and hands it to the drain
+    auto complete_prev = [&]() -> s2k_status {
+        s2k_counts cnt;
+        s2k_status r = finish(ctx, &cnt);
+        for (int attempt = 0; r == S2K_ERR_CAPACITY && attempt < 3; attempt++) { // device arrays too small: exact size, again
+            const uint64_t cap = (cnt.n_minimizers > cnt.n_kminmers ? cnt.n_minimizers : cnt.n_kminmers) + 4096;
+            r = carve_out(ctx, *out_b[prev.slot], prev.n_reads, cap, want_mn, &prev.o);
+            if (r != S2K_OK) return r;
+            r = s2k_extract_device(ctx, (const uint8_t *)in_b[prev.slot]->p, (const uint64_t *)in_o[prev.slot]->p, prev.n_reads,
+                                   prev.n_bases, params, &prev.o, &cnt);
+        }
+        if (r != S2K_OK) return r;
+        prev.cnt = cnt;
+        total.n_minimizers += cnt.n_minimizers;
+        total.n_kminmers += cnt.n_kminmers;
+        total.xor_hash ^= cnt.xor_hash;
+        total.path |= cnt.path;
+        if (B > 1) dr.push(prev);
+        else dr.drain(prev);
+        return S2K_OK;
+    };
+    for (size_t b = 0; b < B; b++) {
+        const int slot = (int)(b & 1);
+        const uint64_t r_lo = cut[b], r_hi = cut[b + 1], nr = r_hi - r_lo;
+        const uint64_t b0 = read_off[r_lo], nbase = read_off[r_hi] - b0;
+        // inputs -> HBM (+ slack so vector loads of the last tile stay inside the allocation); slot b&1 was last read by the
+        // kernels of sub-batch b-2, which complete_prev() of iteration b-1 has waited for
+        hipError_t e = in_b[slot]->ensure(nbase + 256);
+        if (e == hipSuccess) e = in_o[slot]->ensure((nr + 1) * sizeof(uint64_t));
+        if (e != hipSuccess) return bail(fail(ctx, S2K_ERR_DEVICE, "input allocation", e));
+        off.resize(nr + 1);
+        for (uint64_t r = 0; r <= nr; r++) off[r] = read_off[r_lo + r] - b0;
+        // bases cross PCIe packed to 2 bits (exact: every non-ACGT byte travels in a side list), unless the caller opts out
+        if (params->flags & S2K_FLAG_NO_PACK2) e = ctx->stager.h2d(in_b[slot]->p, bases + b0, nbase, s_in);
+        else e = ctx->stager.h2d_packed(in_b[slot]->p, bases + b0, nbase, s_in);
+        if (e == hipSuccess) e = hipMemcpyAsync(in_o[slot]->p, off.data(), (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s_in);
+        if (e == hipSuccess) e = hipStreamSynchronize(s_in);
+        if (e != hipSuccess) return bail(fail(ctx, S2K_ERR_DEVICE, "H2D", e));
+        if (have_prev) {
+            st = complete_prev();
+            if (st != S2K_OK) return bail(st);
+        }
+        dr.wait_slot_free(slot); // the drain of sub-batch b-2 reads out_b[slot]
+        if (dr.err != hipSuccess || dr.nomem) break;
+        prev = SubBatch();
+        prev.slot = slot;
+        prev.r_lo = r_lo;
+        prev.n_reads = nr;
+        prev.n_bases = nbase;
+        st = carve_out(ctx, *out_b[slot], nr, pool_estimate(nbase, nr, params->density, sem.hpc), want_mn, &prev.o);
+        if (st != S2K_OK) return bail(st);
+        dr.mark_busy(slot);
+        st = s2k_extract_device(ctx, (const uint8_t *)in_b[slot]->p, (const uint64_t *)in_o[slot]->p, nr, nbase, params, &prev.o, nullptr);
+        if (st != S2K_OK) return bail(st);
+        have_prev = true;
     }
-    S2K_TQ(3);
-    hipStream_t s = ctx->stream;
-    s2k::HostStager &hs = ctx->stager;
-    hipError_t e = hs.d2h(res->km_off, o.km_off, (n_reads + 1) * 8, s);
-    if (e == hipSuccess) e = hs.d2h(res->hash, o.hash, nk * 8, s);
-    if (e == hipSuccess) e = hs.d2h(res->start, o.start, nk * 4, s);
-    if (e == hipSuccess) e = hs.d2h(res->end, o.end, nk * 4, s);
-    if (e == hipSuccess) e = hs.d2h(res->rev, o.rev, nk, s);
-    if (want_mn) {
-        if (e == hipSuccess) e = hs.d2h(res->mn_off, o.mn_off, (n_reads + 1) * 8, s);
-        if (e == hipSuccess) e = hs.d2h(res->mn_j, o.mn_j, nm * 4, s);
-        if (e == hipSuccess) e = hs.d2h(res->mn_jend, o.mn_jend, nm * 4, s);
-        if (e == hipSuccess) e = hs.d2h(res->mn_hash, o.mn_hash, nm * 4, s);
+    if (have_prev && dr.err == hipSuccess && !dr.nomem) {
+        st = complete_prev();
+        if (st != S2K_OK) return bail(st);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
-        delete ow;
-        memset(res, 0, sizeof *res);
-        return fail(ctx, S2K_ERR_DEVICE, "D2H results", e);
+    if (consumer.joinable()) {
+        dr.close();
+        consumer.join();
     }
+    if (dr.nomem) return bail(fail(ctx, S2K_ERR_NOMEM, "host result allocation"));
+    if (dr.err != hipSuccess) return bail(fail(ctx, S2K_ERR_DEVICE, "D2H results", dr.err));
+    total.n_reads = n_reads;
+    total.n_bases = n_bases;
     res->n_reads = n_reads;
-    res->n_kminmers = nk;
-    res->n_minimizers = want_mn ? nm : 0;
-    res->counts = cnt;
+    res->n_kminmers = total.n_kminmers;
+    res->n_minimizers = want_mn ? total.n_minimizers : 0;
+    res->counts = total;
     res->_owner = ow;
 #ifdef S2K_DEBUG_KNOBS
-    if (trace) {
-        tq[4] = now();
-        fprintf(stderr, "s2k_extract: H2D %.1f ms, kernels %.1f, host alloc %.1f, D2H %.1f, total %.1f ms (%.2f Gbp)\n", tq[1] - tq[0],
-                tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[4] - tq[0], n_bases * 1e-9);
-    }
+    if (trace)
+        fprintf(stderr, "s2k_extract: %zu sub-batch(es), %.1f ms (%.2f Gbp)\n", B,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), n_bases * 1e-9);
 #endif
     return S2K_OK;
 }

@@ -202,6 +202,30 @@ def test_packed_host_transfer_is_exact(eng, oracle):
     assert goth["n"] == refh["n"] and (goth["hash"] == refh["hash"]).all() and (goth["end"] == refh["end"]).all()
 
 
+def test_host_call_is_pipelined_in_sub_batches(eng, oracle):
+    """s2k_extract cuts a call into sub-batches of whole reads and overlaps H2D / kernels / D2H of consecutive ones
+    (s2k_set_host_batch; default 2^29 bases).  With a tiny sub-batch size a small call runs through dozens of them -- empty
+    reads, reads shorter than l, a read longer than a sub-batch, minimizer triples, a result that outgrows the first host
+    allocation -- and must return exactly what one sub-batch returns and what the oracle says."""
+    rng = np.random.default_rng(2024)
+    reads = [rand_read(rng, int(n), hp=0.25, odd=0.01) for n in rng.integers(0, 9000, size=400)]
+    reads[7] = b""
+    reads[8] = b"ACGT"
+    reads[100] = rand_read(rng, 150_000, hp=0.2)  # longer than a sub-batch
+    reads.append(b"")
+    try:
+        for mode in (HM.Hpc, HM.Regular):
+            for d in (0.01, 0.5):
+                eng.set_host_batch(0)
+                one = compare(eng, oracle, reads, 15, 4, d, mode, expect_path=0, tag="one-batch")
+                eng.set_host_batch(40_000)
+                many = compare(eng, oracle, reads, 15, 4, d, mode, expect_path=0, tag="sub-batches")
+                assert one["n"] == many["n"] and one["counts"]["xor_hash"] == many["counts"]["xor_hash"]
+                assert (one["km_off"] == many["km_off"]).all()
+    finally:
+        eng.set_host_batch(0)
+
+
 def test_simd_result_semantics(eng, oracle):
     """SURVEY.md 8a traps (i)-(vi): strict '<', f32 bound, kept last l-mer, start-of-run end, low-nibble
     seeds, dropped final 16-block when #l-mers % 16 == 0."""

@@ -6,6 +6,8 @@ from s2k_loader import import_package
 import torch
 pkg = import_package()
 eng = pkg.Engine(0)
+if os.environ.get('S2K_HOST_BATCH'):
+    eng.set_host_batch(int(os.environ['S2K_HOST_BATCH']))
 n_reads, rl = int(os.environ.get('S2K_PCIE_READS', 400_000)), 10_000
 _d = torch.empty(n_reads * rl + 64, dtype=torch.uint8, device="cuda:0")
 torch.cuda.synchronize()
@@ -29,6 +31,8 @@ for mode in (pkg.HashMode.Regular, pkg.HashMode.Hpc):
     c_extract(mode)  # warm-up (allocations, pinned ring)
     dt, nk = min(c_extract(mode) for _ in range(3))
     print("s2k_extract host->host", mode.name, "%.1f Gbp/s" % (n_reads * rl / dt / 1e9), "kminmers", nk, flush=True)
+if os.environ.get('S2K_PCIE_SKIP_FILE'):
+    sys.exit(0)
 # file mode
 path = "/tmp/s2k_reads.fa"
 with open(path, "wb") as f:
