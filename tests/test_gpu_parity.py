@@ -501,9 +501,10 @@ def _xor_reduce(t):
 
 
 def test_full_size_config2_whole_run_checksums(eng, oracle):
-    """BASELINE config 2 at its full size -- 1 000 000 x 10 kbp = 10 Gbp, l=31 k=10 d=0.01, both scalar modes:
-    every k-min-mer the GPU wrote is folded into count / XOR(hash) / SUM(start) / SUM(end) / #rev and compared with
-    the oracle run over the same 10 Gbp on the host cores (reads generated on the fly on both sides)."""
+    """BASELINE config 2 at its full size -- 1 000 000 x 10 kbp = 10 Gbp, l=31 k=10 d=0.01, all four HashModes (the two
+    scalar ones and the result semantics of Simd / HpcSimd): every k-min-mer the GPU wrote is folded into count /
+    XOR(hash) / SUM(start) / SUM(end) / #rev and compared with the oracle run over the same 10 Gbp on the host cores
+    (reads generated on the fly on both sides)."""
     import os
     import torch
 
@@ -521,7 +522,7 @@ def test_full_size_config2_whole_run_checksums(eng, oracle):
     o.km_capacity = cap
     o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
     threads = max(1, min(os.cpu_count() or 1, 64))
-    for mode in SCALAR:
+    for mode in (HM.Regular, HM.Hpc, HM.Simd, HM.HpcSimd):
         torch.cuda.synchronize()
         c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_reads * L, 31, 10, 0.01, int(mode), o)
         ref = oracle.synth_checksums(seed, n_reads, L, 31, 10, 0.01, OMODE[mode], threads=threads)
