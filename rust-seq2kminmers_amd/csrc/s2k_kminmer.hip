@@ -150,7 +150,7 @@ constexpr int KF_U = 2;              // records per lane per pass
 constexpr int KF_PASS = 64 * KF_U;   // records per pass
 constexpr int KF_TAIL = 64;  // k - 1 <= 64
 
-__global__ __launch_bounds__(64 * KF_WAVES) void kminmer_kernel_fast(
+__global__ __launch_bounds__(64 * KF_WAVES, 8) void kminmer_kernel_fast(
     uint64_t n_tiles, const uint64_t *__restrict__ tile_rec_off, const uint32_t *__restrict__ tile_cnt,
     const uint64_t *__restrict__ tile_goff, Records rec, const uint64_t *__restrict__ mn_off,
     const uint64_t *__restrict__ km_off, uint32_t k, uint64_t km_capacity, uint64_t *__restrict__ o_hash,
