@@ -309,7 +309,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
         mn_cnt = a.take<uint32_t>(n_reads + 1);
         mn_off = o.mn_off ? o.mn_off : a.take<uint64_t>(n_reads + 1);
         scan_tmp = a.take<uint64_t>(scan_tmp_bytes(n_reads > n_tiles ? n_reads : n_tiles) / sizeof(uint64_t) + 1);
-        pool_cursor = a.take<uint64_t>(4);
+        pool_cursor = a.take<uint64_t>(CURSOR_WORDS);
         if (!c.serial) {
             tile_read0 = a.take<uint32_t>(n_tiles + 1);
             tile_cnt = a.take<uint32_t>(n_tiles + 1);
@@ -357,7 +357,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
     }
     S2K_TRY(hipMemsetAsync(ctx->d_counts, 0, sizeof(Counts), st), "memset counts");
     S2K_TRY(hipMemsetAsync(ctx->d_xor, 0, XOR_SHARDS * sizeof(uint64_t), st), "memset xor");
-    S2K_TRY(hipMemsetAsync(pool_cursor, 0, 4 * sizeof(uint64_t), st), "memset cursor");
+    S2K_TRY(hipMemsetAsync(pool_cursor, 0, CURSOR_WORDS * sizeof(uint64_t), st), "memset cursors");
 
     if (c.serial) {
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
@@ -425,6 +425,19 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
         h->n_bases = c.n_bases;
         h->hash_bound = c.bound;
         h->path = c.serial ? 1u : 0u;
+        if (c.sem.dbg_skip & 32) // KNOBS builds: spread of the waves' finishing times in the tiled kernel
+        {
+            fprintf(stderr, "[s2k dbg] last wave finished %.1f us after the first\n", (double)(h->dbg_cycles[0][0] - ~h->dbg_cycles[0][1]) * 0.01);
+#ifdef S2K_DEBUG_KNOBS
+            if (const char *path = getenv("S2K_DEBUG_WAVE_DUMP")) {
+                if (FILE *f = fopen(path, "w")) {
+                    for (int i = 0; i < 4096; i++)
+                        if (h->dbg_wave[i][0]) fprintf(f, "%d %llu %u %u\n", i, (unsigned long long)(h->dbg_wave[i][0] - ~h->dbg_cycles[0][1]), (unsigned)(h->dbg_wave[i][1] >> 32), (unsigned)h->dbg_wave[i][1]);
+                    fclose(f);
+                }
+            }
+#endif
+        }
         if (c.sem.dbg_skip & 8) {
             fprintf(stderr, "[s2k dbg] phase cycles (sum over waves):");
             for (int i = 0; i < 16; i++) {

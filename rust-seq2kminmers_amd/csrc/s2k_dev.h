@@ -63,6 +63,9 @@ struct Counts { // mirrored by s2k_counts (include/s2k.h)
     uint64_t pool_needed;
     uint32_t pool_overflow, non_ascii, km_overflow, mn_overflow;
     uint64_t dbg_cycles[64][16]; // S2K_DEBUG_SKIP & 8: shader-clock cycles per phase, summed over waves
+#ifdef S2K_DEBUG_KNOBS
+    uint64_t dbg_wave[4096][2];  // S2K_DEBUG_SKIP & 32: per wave {finish time (100 MHz) , XCC_ID << 32 | HW_ID}
+#endif
 };
 
 constexpr int XOR_SHARDS = 4096;
@@ -70,6 +73,10 @@ constexpr int XOR_SHARDS = 4096;
 // tile geometry of the tiled minimizer kernel (s2k_tile.hip)
 constexpr int TILE_T = 144;              // bases per lane
 constexpr int TILE_BASES = 64 * TILE_T;  // 9216 bases per wave-tile
+// cursors of the tiled kernel's dynamic tile deal (one per lane of a wave that looks for an open one); they follow the
+// overflow-pool cursor in one zeroed array: word 0 = pool cursor, cursor g = word 16 + 16 g (128 B apart)
+constexpr int TILE_CURSORS = 64;
+constexpr int CURSOR_WORDS = 16 + 16 * TILE_CURSORS;
 
 // Orders LDS traffic between the lanes of ONE wave (no workgroup barrier: waves of a block run independent
 // tiles with different trip counts).  A wave's DS operations execute in program order, so waiting for the

@@ -324,11 +324,15 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
     else hash_loop_dynamic(D, tab, bound, lane, l, np, caps, raw);
 }
 
-// Dynamic dealing of tiles (one atomicAdd on a device-wide cursor per tile, taken two iterations ahead) was measured and
-// lost: 1.085 M atomics on ONE address from eight XCDs are serialised at ~12 ns each, the kernel took 13.2 ms in both modes
-// (static dealing: 8.2 / 5.9 ms).  Kept as a compile-time experiment (-DS2K_DYNAMIC_TILES=1); tiles are dealt round-robin.
+// Tiles are dealt DYNAMICALLY.  The SIMD's issue arbiter serves the oldest wave first: with a static deal (every wave the
+// same number of tiles) the first-launched wave of each SIMD ran out of tiles 3.7 ms before the last-launched one, and the
+// SIMDs spent the last third of the kernel with two, then one wave (tools/tail_spread.sh, profiles/r02_zz_tail_spread.txt).
+// A wave takes its first three tiles statically (the software pipeline is three deep) and every later one from one of
+// TILE_CURSORS cursors in global memory, two iterations before it processes it; when its cursor runs dry it moves on to
+// one that is not.  (ONE cursor for all waves was measured first: 1.085 M atomics on one address are serialised at ~12 ns
+// each and the kernel took 13.2 ms; 64 addresses, 128 B apart, are not a bottleneck.)
 #ifndef S2K_DYNAMIC_TILES
-#define S2K_DYNAMIC_TILES 0
+#define S2K_DYNAMIC_TILES 1
 #endif
 
 // Phase stamps (cycles per phase, kept in registers and flushed once per tile to one of 64 shards) exist only in
@@ -1041,9 +1045,27 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         prefetch(t);
         have_pre = true;
     }
-    // tn / tnn: the next two tiles of this wave (t + n_waves, t + 2 n_waves; with S2K_DYNAMIC_TILES every tile after the first
-    // three comes from the cursor pool_cursor[1], zeroed by the host before the launch)
-    uint64_t tn = t + n_waves, tnn = t + 2 * n_waves; // >= n_tiles: none
+    // tn / tnn: the next two tiles of this wave; >= n_tiles: none.  Dynamic tiles are numbered from dyn0 on: cursor g deals
+    // dyn0 + g, dyn0 + g + TILE_CURSORS, ... (pool_cursor[16 + 16 g], zeroed by the host before the launch).
+    uint64_t tn = t + n_waves, tnn = t + 2 * n_waves;
+    const uint64_t dyn0 = 3 * n_waves;
+    uint32_t cur_g = (uint32_t)((blockIdx.x * TW + w) % TILE_CURSORS);
+    unsigned long long *const cursors = (unsigned long long *)pool_cursor + 16;
+    // the cursor this wave draws from is dry: look at all of them, move to the next one (cyclically) that is not, draw there
+    auto draw_elsewhere = [&]() -> uint64_t {
+        for (;;) {
+            const uint64_t left_g = dyn0 + (uint64_t)lane < n_tiles ? (n_tiles - dyn0 - lane + TILE_CURSORS - 1) / TILE_CURSORS : 0; // tiles cursor `lane` deals
+            const unsigned long long seen = __hip_atomic_load(&cursors[16 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t open = __ballot(seen < left_g);
+            if (!open) return ~0ull;
+            const uint64_t after = open & ~((2ull << cur_g) - 1ull);
+            cur_g = (uint32_t)__builtin_ctzll(after ? after : open);
+            unsigned long long got = 0;
+            if (lane == 0) got = atomicAdd(&cursors[16 * cur_g], 1ull);
+            const uint64_t tile = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
+            if (tile < n_tiles) return tile;
+        }
+    };
     uint32_t r0n = 0, r1n = 0;
     if (tn < n_tiles) {
         r0n = tile_read0[tn];
@@ -1051,8 +1073,8 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     }
 
     for (; t < n_tiles;) {
-        uint32_t took = 0; // the tile after tnn
-        if (S2K_DYNAMIC_TILES && lane == 0 && tnn < n_tiles) took = (uint32_t)atomicAdd((unsigned long long *)&pool_cursor[1], 1ull);
+        uint32_t took = 0; // draw for the tile after tnn: issued here, looked at when the pipeline rotates
+        if (S2K_DYNAMIC_TILES && lane == 0 && tnn < n_tiles) took = (uint32_t)atomicAdd(&cursors[16 * cur_g], 1ull);
         const uint64_t t0 = t * (uint64_t)TILE_BASES;
         l16_tile = 16 * lane;
         // Regular: opaque, so that the staging / prefetch addresses are formed per tile instead of living in 20 hoisted
@@ -1155,6 +1177,11 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
             __builtin_amdgcn_sched_barrier(0);
             S2K_STAMP(2); // hash loop
         }
+        // the draw made at the top of the iteration is looked at HERE: everything older than it in the vector-memory queue had
+        // the whole hash loop to finish, whereas at the end of the iteration a wait for it would also drain this tile's stores
+        uint64_t drawn = ~0ull;
+        if (S2K_DYNAMIC_TILES && tnn < n_tiles)
+            drawn = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)took);
         issue_next(); // after the hash loop: 40 staging registers live across it would not fit three waves per SIMD
         if (nh != 0 && sem.enabled) {
 #ifndef EXP_NODENSE
@@ -1172,13 +1199,31 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; // rotate the pipeline
         t = tn;
         tn = tnn;
-        if (S2K_DYNAMIC_TILES) tnn = tnn < n_tiles ? 3 * n_waves + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)took) : tnn;
-        else tnn += n_waves;
+        if (S2K_DYNAMIC_TILES) {
+            if (tnn < n_tiles) {
+                tnn = drawn;
+                if (tnn >= n_tiles) tnn = draw_elsewhere();
+            }
+        } else {
+            tnn += n_waves;
+        }
         S2K_STAMP(6); // tail
     }
 #ifdef S2K_PROFILE
     if ((sem.dbg_skip & 8) && lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd((unsigned long long *)&counts->dbg_cycles[blockIdx.x & 63][i], (unsigned long long)ph[i]);
+#endif
+#ifdef S2K_DEBUG_KNOBS // S2K_DEBUG_SKIP & 32: when did the first and the last wave run out of tiles (100 MHz clock)?
+    if ((sem.dbg_skip & 32) && lane == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        atomicMax((unsigned long long *)&counts->dbg_cycles[0][0], now);
+        atomicMax((unsigned long long *)&counts->dbg_cycles[0][1], ~now);
+        const uint32_t wid = blockIdx.x * TW + w;
+        if (wid < 4096) {
+            counts->dbg_wave[wid][0] = now;
+            counts->dbg_wave[wid][1] = ((uint64_t)__builtin_amdgcn_s_getreg((20 | (0 << 6) | (31 << 11))) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((4 | (0 << 6) | (31 << 11)));
+        }
+    }
 #endif
 }
 
