@@ -334,6 +334,17 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
 #ifndef S2K_DYNAMIC_TILES
 #define S2K_DYNAMIC_TILES 1
 #endif
+// s_setprio per phase (0..3; the arbiter prefers higher, then older waves)
+#ifndef S2K_PRIO_STAGE
+#define S2K_PRIO_STAGE 0
+#endif
+#ifndef S2K_PRIO_HASH
+#define S2K_PRIO_HASH 0
+#endif
+#ifndef S2K_PRIO_DENSE
+#define S2K_PRIO_DENSE 0
+#endif
+#define S2K_SETPRIO(p) do { if (S2K_PRIO_STAGE | S2K_PRIO_HASH | S2K_PRIO_DENSE) __builtin_amdgcn_s_setprio(p); } while (0)
 
 // Phase stamps (cycles per phase, kept in registers and flushed once per tile to one of 64 shards) exist only in
 // builds with -DS2K_PROFILE (tools/phases.sh): the 16 accumulators cost 32 VGPRs that production kernels need.
@@ -1076,6 +1087,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         uint32_t took = 0; // draw for the tile after tnn: issued here, looked at when the pipeline rotates
         if (S2K_DYNAMIC_TILES && lane == 0 && tnn < n_tiles) took = (uint32_t)atomicAdd(&cursors[16 * cur_g], 1ull);
         const uint64_t t0 = t * (uint64_t)TILE_BASES;
+        S2K_SETPRIO(S2K_PRIO_STAGE);
         l16_tile = 16 * lane;
         // Regular: opaque, so that the staging / prefetch addresses are formed per tile instead of living in 20 hoisted
         // VGPRs (150 VGPRs, no spills, -1.3 %); the Hpc kernel measured 2 % faster WITH the hoisted addresses and their reloads
@@ -1171,6 +1183,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         if (nh != 0 && sem.enabled) {
             // ---- the hot loop ------------------------------------------------------------------------------
 #ifndef EXP_NOHASH
+            S2K_SETPRIO(S2K_PRIO_HASH);
             if (!(sem.dbg_skip & 1)) hash_stage<L, HPC>(D, tab, sem.bound_le, lane, l, np, caps, raw);
 #endif
             wave_sync();
@@ -1179,6 +1192,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         }
         // the draw made at the top of the iteration is looked at HERE: everything older than it in the vector-memory queue had
         // the whole hash loop to finish, whereas at the end of the iteration a wait for it would also drain this tile's stores
+        S2K_SETPRIO(S2K_PRIO_DENSE);
         uint64_t drawn = ~0ull;
         if (S2K_DYNAMIC_TILES && tnn < n_tiles)
             drawn = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)took);

@@ -50,12 +50,13 @@ for mode in ("hpc", "regular"):
         f_kb, w_kb = vals.get("FETCH_SIZE", 0.0), vals.get("WRITE_SIZE", 0.0)
         per_kernel[k] = {"launches_per_step": calls_per_step, "fetch_size_kb": f_kb, "write_size_kb": w_kb,
                          "hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024)}
+        if "synth_kernel" in k or "at::native" in k or "elementwise_kernel" in k: continue  # run once per process, not per step
         fetch += f_kb * calls_per_step; write += w_kb * calls_per_step
     open(out + "/%s_pmc_summary.txt" % mode, "w").write("\n".join(lines) + "\n")
     res[mode] = {"mode": mode, "n_bases": 10000000000, "hbm_bytes_per_step": int((2 * fetch + write) * 1024),
                  "fetch_size_kb_per_step": fetch, "write_size_kb_per_step": write, "kernels": per_kernel,
                  "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on python3 bench.py --steps 2 --warmup 1 --mode %s --no-other-mode; "
-                           "sum over ALL kernels of one step; FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE exact; collected %s" % (mode, os.popen("date -u +%Y-%m-%dT%H:%MZ").read().strip())}
+                           "sum over all kernels of one step (input generator and torch's own kernels left out); FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE exact; collected %s" % (mode, os.popen("date -u +%Y-%m-%dT%H:%MZ").read().strip())}
     print(mode, "HBM bytes per step", res[mode]["hbm_bytes_per_step"])
 json.dump(res["hpc"], open(out + "/traffic_hpc.json", "w"), indent=1)
 json.dump(res["regular"], open(out + "/traffic_regular.json", "w"), indent=1)
