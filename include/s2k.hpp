@@ -73,6 +73,11 @@ class Engine { // one per thread and device (like one KminmersIterator per threa
     Engine &operator=(const Engine &) = delete;
     ~Engine() { s2k_destroy(ctx_); }
 
+    // bases per sub-batch of extract(): H2D / kernels / D2H of consecutive sub-batches overlap (0 = default, 2^29)
+    void set_host_batch(uint64_t bases) {
+        s2k_status st = s2k_set_host_batch(ctx_, bases);
+        if (st != S2K_OK) throw Error(st, s2k_strerror(st));
+    }
     Batch extract(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, size_t l, size_t k, double density,
                   HashMode mode, uint32_t flags = 0) {
         s2k_params p{(uint32_t)l, (uint32_t)k, density, (int32_t)mode, flags};
