@@ -754,7 +754,7 @@ struct Drain { // the s2k_result under construction and the thread that fills it
         }
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
-            err = e;
+            err.store(e);
             return;
         }
         if (used_k)

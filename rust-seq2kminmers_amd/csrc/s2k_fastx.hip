@@ -437,6 +437,7 @@ s2k_status s2k_run_file(s2k_ctx *ctx, const char *path, const s2k_params *params
     };
 
     int cur = 0;
+    bool try_pack = !(params->flags & S2K_FLAG_NO_PACK2);
     while (st == S2K_OK && pos < fsize) {
         const uint64_t end = find_record_start(fw, pos, pos + chunk, fastq == 1);
         const uint64_t n = end - pos;
@@ -452,7 +453,7 @@ s2k_status s2k_run_file(s2k_ctx *ctx, const char *path, const s2k_params *params
         }
         // file -> pinned ring (several threads pread disjoint ranges) -> HBM, then the record splitter, all on copy_stream
         const uint64_t file_off = pos;
-        hipError_t e = s2k::ctx_stager(ctx).h2d_fill(d.raw, n, copy_stream, [&](char *dst, size_t off, size_t len) {
+        const std::function<bool(char *, size_t, size_t)> from_file = [&](char *dst, size_t off, size_t len) {
             while (len) {
                 const ssize_t got = pread(fd, dst, len, (off_t)(file_off + off));
                 if (got <= 0) return false;
@@ -461,7 +462,18 @@ s2k_status s2k_run_file(s2k_ctx *ctx, const char *path, const s2k_params *params
                 len -= (size_t)got;
             }
             return true;
-        });
+        };
+        // FASTA text is DNA plus a header and a newline now and then: it crosses the link 2-bit packed, the other bytes as
+        // exceptions, and is rebuilt byte for byte in HBM before the splitter sees it.  FASTQ (half of it quality strings) does
+        // not pack: after the first batch that did not, the text is staged as it is.
+        hipError_t e;
+        if (try_pack) {
+            bool packed_any = false;
+            e = s2k::ctx_stager(ctx).h2d_packed_fill(d.raw, n, copy_stream, from_file, &packed_any);
+            if (!packed_any && n >= (8u << 20)) try_pack = false;
+        } else {
+            e = s2k::ctx_stager(ctx).h2d_fill(d.raw, n, copy_stream, from_file);
+        }
         if (e == hipSuccess) e = s2k::fx_parse_count((const uint8_t *)d.raw, n, fastq == 1, d.ws, d_tot, copy_stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h_tot, d_tot, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, copy_stream);
         if (e == hipSuccess) e = hipStreamSynchronize(copy_stream);

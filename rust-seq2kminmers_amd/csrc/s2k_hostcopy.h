@@ -59,6 +59,10 @@ public:
     // ASCII stream in dst_dev (which must be 16-byte aligned).  A chunk with more than ~3 % exceptions (lower-case text,
     // quality strings ...) is sent as it is.  SURVEY.md 8f-1: "host-side 2-bit packing to cut PCIe bytes 4x".
     hipError_t h2d_packed(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);
+    // same for a source that is produced piecewise (a file: FASTA text is DNA with ~0.1-2 % other bytes, which travel as
+    // exceptions); *packed_any tells whether any chunk went packed (FASTQ never does: the caller stops asking)
+    hipError_t h2d_packed_fill(void *dst_dev, size_t bytes, hipStream_t s, const std::function<bool(char *, size_t, size_t)> &fill,
+                               bool *packed_any);
     // device -> pageable host, ordered after the work already queued on `s`.  On return `dst` is complete.
     hipError_t d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
 
@@ -68,6 +72,8 @@ public:
 
 private:
     hipError_t init();
+    hipError_t packed_impl(void *dst_dev, const uint8_t *src, const std::function<bool(char *, size_t, size_t)> *fill, size_t bytes,
+                           hipStream_t s, bool *packed_any);
     bool ready_ = false;
     char *dpack_[kSlots] = {}; // device staging of the packed chunks (h2d_packed)
     char *pin_[kSlots] = {};

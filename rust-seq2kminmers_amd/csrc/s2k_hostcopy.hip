@@ -271,35 +271,67 @@ __global__ __launch_bounds__(256) void patch_exceptions_kernel(const Exc *__rest
 } // namespace
 
 hipError_t HostStager::h2d_packed(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) {
-    if (bytes < (8u << 20) || ((uintptr_t)dst_dev & 15u) != 0) return h2d(dst_dev, src_host, bytes, s);
+    return packed_impl(dst_dev, (const uint8_t *)src_host, nullptr, bytes, s, nullptr);
+}
+
+hipError_t HostStager::h2d_packed_fill(void *dst_dev, size_t bytes, hipStream_t s, const std::function<bool(char *, size_t, size_t)> &fill,
+                                       bool *packed_any) {
+    return packed_impl(dst_dev, nullptr, &fill, bytes, s, packed_any);
+}
+
+// src != nullptr: the source is host memory; else fill(dst, offset, n) produces source bytes [offset, offset + n) (a file):
+// every copy thread reads its slice into a scratch buffer of its own and packs from there
+hipError_t HostStager::packed_impl(void *dst_dev, const uint8_t *src, const std::function<bool(char *, size_t, size_t)> *fill, size_t bytes,
+                                   hipStream_t s, bool *packed_any) {
+    if (packed_any) *packed_any = false;
+    if (bytes < (8u << 20) || ((uintptr_t)dst_dev & 15u) != 0) return src ? h2d(dst_dev, src, bytes, s) : h2d_fill(dst_dev, bytes, s, *fill);
     hipError_t e = init();
     if (e != hipSuccess) return e;
     constexpr size_t kHalf = kChunk / 2;  // pinned chunk = [packed bases | exception lists]
     constexpr size_t kSrc = 4 * kHalf;    // source bytes per chunk (64 MiB)
     for (int i = 0; i < kSlots; i++)
         if (!dpack_[i] && (e = hipMalloc((void **)&dpack_[i], kChunk)) != hipSuccess) return e;
-    const uint8_t *src = (const uint8_t *)src_host;
     size_t off = 0;
     for (int i = 0; off < bytes; i++) {
         const int slot = i % kSlots;
         const size_t n = bytes - off < kSrc ? bytes - off : kSrc;
         if ((e = hipEventSynchronize(ev_[slot])) != hipSuccess) return e;
         char *pin = pin_[slot];
-        std::atomic<bool> overflow{false};
+        std::atomic<bool> overflow{false}, failed{false};
         // every slice packs its part and keeps its exceptions in the matching part of the second half: [count u64][entries]
         pool_->slices(n, [&](size_t b, size_t en) {
+            const uint8_t *from;
+            if (src) {
+                from = src + off + b;
+            } else {
+                thread_local std::vector<uint8_t> scratch;
+                if (scratch.size() < en - b) scratch.resize(en - b);
+                if (!(*fill)((char *)scratch.data(), off + b, en - b)) {
+                    failed = true;
+                    return;
+                }
+                from = scratch.data();
+            }
             char *region = pin + kHalf + b / 4;
             const size_t cap = (en - b) / 4 >= 16 ? ((en - b) / 4 - 8) / sizeof(Exc) : 0;
-            const size_t ne = pack2(src + off + b, en - b, (uint8_t *)pin + b / 4, (Exc *)(region + 8), cap, (uint32_t)b);
+            const size_t ne = pack2(from, en - b, (uint8_t *)pin + b / 4, (Exc *)(region + 8), cap, (uint32_t)b);
             if (ne == SIZE_MAX) overflow = true;
             else memcpy(region, &ne, 8);
         });
+        if (failed) return hipErrorUnknown;
         if (overflow) { // not DNA text: this chunk goes as it is (two pinned chunks' worth at most)
             if ((e = hipEventRecord(ev_[slot], s)) != hipSuccess) return e;
-            if ((e = h2d((char *)dst_dev + off, src + off, n, s)) != hipSuccess) return e;
+            if (src) {
+                e = h2d((char *)dst_dev + off, src + off, n, s);
+            } else {
+                const size_t base = off;
+                e = h2d_fill((char *)dst_dev + off, n, s, [&](char *d, size_t o, size_t len) { return (*fill)(d, base + o, len); });
+            }
+            if (e != hipSuccess) return e;
             off += n;
             continue;
         }
+        if (packed_any) *packed_any = true;
         // gather the slices' exception lists behind the packed bytes (few entries; one thread)
         size_t n_exc = 0;
         {

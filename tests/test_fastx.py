@@ -178,6 +178,23 @@ def test_run_file_many_batches_fasta_and_fastq(tmp_path, oracle):
         for batch in (1 << 20, 1 << 30):
             tot = eng.run_file(str(path), 31, 7, 0.01, pkg.HashMode.Hpc, batch_bases=batch)
             assert (tot["n_reads"], tot["n_bases"], tot["n_kminmers"], tot["xor_hash"]) == want, (path.name, batch)
+    # a file of several pinned chunks: FASTA text crosses PCIe 2-bit packed (headers, newlines, N runs and a lower-case
+    # stretch travel as exceptions; the chunk that is mostly lower case goes as it is) and must arrive byte for byte
+    big = []
+    for i in range(12):
+        a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(rng.integers(1_500_000, 3_500_000)))].copy()
+        for q in rng.integers(0, len(a) - 200, size=40):
+            a[q:q + int(rng.integers(1, 150))] = ord("N")
+        if i in (5, 6):
+            a |= 0x20
+        big.append(a.tobytes())
+    bb, bo = pkg.pack_reads(big)
+    rb = oracle.batch(bb, bo, 31, 7, 0.01, so.HPC, threads=8)
+    bf = tmp_path / "big.fa"
+    _write_fasta(bf, big, width=70)
+    for flags in (0, pkg.FLAG_NO_PACK2):
+        tot = eng.run_file(str(bf), 31, 7, 0.01, pkg.HashMode.Hpc, flags=flags)
+        assert (tot["n_reads"], tot["n_bases"], tot["n_kminmers"], tot["xor_hash"]) == (len(big), len(bb), rb["n"], int(np.bitwise_xor.reduce(rb["hash"]))), flags
     # low-complexity input: far more k-min-mers than the density-based capacity guess -> exact retry inside the driver
     lc = tmp_path / "lc.fa"
     reads2 = [b"ACGT" * 20000 for _ in range(40)]
