@@ -598,8 +598,8 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
 
 // Dense phase of one tile: hit bitmasks -> validated, ordered minimizer records.  Returns the number of
 // records (tile_cnt) and sets `base` (tile_rec_off).  See the file header for the idea.
-template <int L, bool HPC, class WL>
-__device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const uint2 *tab,
+template <int L, bool HPC, class WL, class IssueNext>
+__device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, const uint8_t *D, const uint2 *tab,
                                                 const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t t,
                                                 uint64_t t0, uint32_t tile_len, uint32_t nh, uint32_t halo_n,
                                                 uint32_t Tq, uint32_t l, uint32_t r0, uint32_t r1, uint64_t bpos0,
@@ -752,7 +752,10 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
     const uint32_t myoff = incl - cnt;
     const uint32_t N = bcast(incl, 63); // valid minimizers of this tile
     base = t * rec.slab_cap;
-    if (N == 0) return 0;
+    if (N == 0) {
+        issue_next();
+        return 0;
+    }
     if (N > rec.slab_cap) { // rare: more hits than the per-tile slab holds
         uint64_t got = 0;
         if (lane == 0) got = atomicAdd((unsigned long long *)pool_cursor, (unsigned long long)N);
@@ -764,6 +767,7 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
                 atomicMax((unsigned long long *)&counts->pool_needed, (unsigned long long)(got + N));
             }
             base = 0;
+            issue_next();
             return 0;
         }
     }
@@ -875,48 +879,52 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
         wave_sync();
         S2K_STAMP(4); // scan + list
         const uint32_t bn = N - b0 < (uint32_t)LISTCAP ? N - b0 : (uint32_t)LISTCAP;
+        // hits that were not the last raw hit of their piece (~7 %) have no kept hash: they are queued and re-derived from
+        // their l bytes (closed form, src/nthash_hpc.rs:144,168) BEFORE the rounds, so that the tile's bytes are dead from here
+        // on and the next tile can be loaded straight into them (global -> LDS, no registers) while the rounds run
+        for (uint32_t k0 = 0; k0 < bn; k0 += 64) {
+            const uint32_t kq = k0 + lane;
+            const uint32_t e = kq < bn ? S.list[kq] : 0u;
+            const bool need = (e & 0x8000u) != 0;
+            uint64_t jobs = __ballot(need);
+#ifdef S2K_PROFILE
+            if (sem.dbg_skip & 8) ph[7] += (uint64_t)__popcll(jobs);
+#endif
+            if (sem.dbg_skip & 64) jobs = 0;
+            while (jobs) { // wave-uniform: queue up to JOBCAP jobs, flush, queue the rest
+                const uint32_t room = (uint32_t)JOBCAP - njobs;
+                const uint32_t rank = (uint32_t)__popcll(jobs & ((1ull << lane) - 1ull));
+                const bool mine = need && ((jobs >> lane) & 1ull) && rank < room;
+                if (mine) {
+                    S.jobx[njobs + rank] = (uint16_t)(e & 0x3FFFu);
+                    S.jobslot[njobs + rank] = b0 + kq;
+                }
+                const uint64_t done = __ballot(mine);
+                njobs += (uint32_t)__popcll(done);
+                jobs &= ~done;
+                if (jobs) flush_jobs();
+            }
+        }
+        if (njobs) flush_jobs();
+        S2K_STAMP(12); // hash re-derivation
+        if (b0 + (uint32_t)LISTCAP >= N) issue_next();
         auto rounds = [&](auto many_c) {
         constexpr bool MANY = decltype(many_c)::value;
         constexpr int U = 1; // hits per lane per iteration (two overlapped back-maps cost ~25 VGPRs: three waves per SIMD matter more)
         for (uint32_t k0 = 0; k0 < bn; k0 += 64 * U) {
             uint32_t kk[U], x[U], rid[U];
-            bool act[U], need_re[U];
+            bool act[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 kk[u] = k0 + 64 * u + lane;
                 act[u] = kk[u] < bn;
                 x[u] = rid[u] = 0;
-                need_re[u] = false;
                 if (act[u]) {
                     const uint32_t e = S.list[kk[u]];
                     x[u] = e & 0x3FFFu;
-                    need_re[u] = (e & 0x8000u) != 0;
                 }
             }
-            // hits that were not the last raw hit of their piece (~7 %) have no kept hash: queue them; one lane
-            // per queued hit re-derives it from the l bytes (closed form, src/nthash_hpc.rs:144,168)
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                uint64_t jobs = __ballot(need_re[u]);
-#ifdef S2K_PROFILE
-                if (sem.dbg_skip & 8) ph[7] += (uint64_t)__popcll(jobs);
-#endif
-                if (sem.dbg_skip & 64) jobs = 0;
-                while (jobs) { // wave-uniform: queue up to JOBCAP jobs, flush, queue the rest
-                    const uint32_t room = (uint32_t)JOBCAP - njobs;
-                    const uint32_t rank = (uint32_t)__popcll(jobs & ((1ull << lane) - 1ull));
-                    const bool mine = need_re[u] && ((jobs >> lane) & 1ull) && rank < room;
-                    if (mine) {
-                        S.jobx[njobs + rank] = (uint16_t)x[u];
-                        S.jobslot[njobs + rank] = b0 + kk[u];
-                    }
-                    const uint64_t done = __ballot(mine);
-                    njobs += (uint32_t)__popcll(done);
-                    jobs &= ~done;
-                    if (jobs) flush_jobs();
-                }
-            }
-            S2K_STAMP(8); // round: list read, kept hash, job queueing
+            S2K_STAMP(8); // round: list read
             uint64_t p[U], e1[U]; // stream position of the l-mer start; position of the last base that belongs to it
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -985,8 +993,6 @@ __device__ __forceinline__ uint32_t dense_phase(WL &S, const uint8_t *D, const u
         if (many) rounds(std::true_type{});
         else rounds(std::false_type{});
     }
-    if (njobs) flush_jobs();
-    S2K_STAMP(12); // hash re-derivation
     return N;
 }
 
@@ -1023,26 +1029,27 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
 
     // a tile is "full" when the tile and its 128 B look-ahead lie inside the stream: staged branch-free
     auto is_full = [&](uint64_t tt) { return (tt + 1) * (uint64_t)TILE_BASES + 128 <= n_bases; };
-    // Software pipeline over this wave's tiles (cur = t, nxt = t + n_waves, nn = t + 2 n_waves):
-    //   pre[], prevb      : bases of nxt, issued while cur is hashed
-    //   r0n, r1n          : tile_read0 of nxt   (issued one iteration earlier, so their values are usable ...)
-    //   bposn, rs0n       : read_off[r0n + 1 + lane], read_off[r0n]   (... to address these, issued with pre[])
-    //   r0nn, r1nn        : tile_read0 of nn
+    // Software pipeline over this wave's tiles (cur = t, then tn, then tnn):
+    //   the bases of tn   : loaded straight into this wave's LDS buffer (global_load_lds_dwordx4: no registers, no ds_write)
+    //                       as soon as the dense phase of cur has re-derived its queued hashes, i.e. no longer reads the buffer;
+    //                       the one-lane-per-hit rounds that follow cover the latency
+    //   prevb             : the byte before tn, with them
+    //   r0n, r1n          : tile_read0 of tn    (issued one iteration earlier, so their values are usable ...)
+    //   bposn, rs0n       : read_off[r0n + 1 + lane], read_off[r0n]   (... to address these, issued with the bases)
+    //   r0nn, r1nn        : tile_read0 of tnn
     // so no dependent global load is waited for on the spot after the prologue.
-    uint4 pre[NPRE];
     uint32_t prevb = 0;
     bool have_pre = false;
-    uint32_t l16_tile = 16 * lane; // re-made opaque at the top of every tile (see there)
-    if constexpr (!HPC) asm volatile("" : "+v"(l16_tile));
+    typedef __attribute__((address_space(3))) uint8_t lds_u8s;
     auto prefetch = [&](uint64_t tt) { // issue the loads for tile tt; nothing waits here
-        const uint8_t *g = bases + tt * (uint64_t)TILE_BASES;
-        const uint32_t l16 = l16_tile; // opaque per tile: otherwise the ten 64-bit lane addresses are hoisted out of the tile loop (20 VGPRs, spilled)
+        const uint8_t *g = bases + tt * (uint64_t)TILE_BASES + 16 * lane;
+        lds_u8s *dl = (lds_u8s *)D; // wave-uniform: lane i of a load lands at base + 16 i (tools/experiments/lds_direct_test.hip)
 #pragma unroll
-        for (int r = 0; r < NPRE; r++) {
-            const uint32_t off = l16 + 1024 * r;
-            pre[r] = (r < NPRE - 1 || lane < 8) ? *reinterpret_cast<const uint4 *>(g + off) : make_uint4(0, 0, 0, 0);
-        }
-        prevb = tt > 0 ? (uint32_t)g[-1] : 0u;
+        for (int r = 0; r < NPRE; r++)
+            if (r < NPRE - 1 || lane < 8)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + 1024 * r),
+                                                 (__attribute__((address_space(3))) void *)(dl + 1024 * r), 16, 0, 0);
+        prevb = tt > 0 ? (uint32_t)bases[tt * (uint64_t)TILE_BASES - 1] : 0u;
     };
     auto read_entries = [&](uint32_t rr0, uint64_t &bp, uint64_t &rs) {
         const uint64_t bri = (uint64_t)rr0 + 1 + lane;
@@ -1088,29 +1095,15 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         if (S2K_DYNAMIC_TILES && lane == 0 && tnn < n_tiles) took = (uint32_t)atomicAdd(&cursors[16 * cur_g], 1ull);
         const uint64_t t0 = t * (uint64_t)TILE_BASES;
         S2K_SETPRIO(S2K_PRIO_STAGE);
-        l16_tile = 16 * lane;
-        // Regular: opaque, so that the staging / prefetch addresses are formed per tile instead of living in 20 hoisted
-        // VGPRs (150 VGPRs, no spills, -1.3 %); the Hpc kernel measured 2 % faster WITH the hoisted addresses and their reloads
-        if constexpr (!HPC) asm volatile("" : "+v"(l16_tile));
         const uint64_t rem = n_bases - t0;
         const uint32_t avail = rem > (uint64_t)(TILE_BASES + 128) ? (uint32_t)(TILE_BASES + 128) : (uint32_t)rem;
         const uint32_t tile_len = rem > (uint64_t)TILE_BASES ? (uint32_t)TILE_BASES : (uint32_t)rem;
-        // ---- stage the tile (+128 B look-ahead) in LDS: 1 KiB per wave-instruction ----------------------
+        // ---- the tile (+128 B look-ahead) in LDS ------------------------------------------------------------------
+        uint32_t l16_tile = 16 * lane;
         if (have_pre) {
-            // LDS address space + one 32-bit lane address: the 1 KiB steps ride in the ds_write immediates (as generic
-            // pointers the ten addresses were 64-bit loop invariants: 20 VGPRs, spilled in the Hpc kernel)
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            typedef __attribute__((address_space(3))) u32x4 lds_u4;
-            typedef __attribute__((address_space(3))) uint8_t lds_u8s;
-            const uint32_t dl = (uint32_t)(uintptr_t)(lds_u8s *)D + l16_tile;
-#pragma unroll
-            for (int r = 0; r < NPRE; r++) {
-                if constexpr (HPC) {
-                    if (r < NPRE - 1 || lane < 8) *reinterpret_cast<uint4 *>(D + 16 * lane + 1024 * r) = pre[r];
-                } else {
-                    if (r < NPRE - 1 || lane < 8) *reinterpret_cast<lds_u4 *>(dl + 1024 * r) = u32x4{pre[r].x, pre[r].y, pre[r].z, pre[r].w};
-                }
-            }
+            // loaded into the buffer by the previous iteration (prologue: just now): wait for the loads, nothing to move
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         } else { // tile at the end of the stream: guarded loads, zero past the end
             const uint8_t *g = bases + t0;
             for (int r = 0; r < NPRE; r++) {
@@ -1150,7 +1143,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
             np = need <= 1 ? 1 : need <= 3 ? 3 : need <= 5 ? 5 : need <= 7 ? 7 : 9;
         }
         S2K_STAMP(1); // hpc compaction
-        // ---- next tile's loads: issued right after the hash loop; the dense phase covers their latency ----------
+        // ---- next tile's loads (see issue_once below) ----------------------------------------------------------------
         uint64_t bposn = ~0ull, rs0n = 0;
         uint32_t r0nn = 0, r1nn = 0;
         auto issue_next = [&]() {
@@ -1166,11 +1159,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
                     r1nn = tile_read0[tnn + 1];
                 }
             }
-            if (!have_pre) { // tell the compiler the staged registers are dead (they would stay live across the whole loop body)
-#pragma unroll
-                for (int r = 0; r < NPRE; r++) pre[r] = make_uint4(0, 0, 0, 0);
-                prevb = 0;
-            }
+            if (!have_pre) prevb = 0;
         };
         const uint32_t Tq = 16 * np;
         uint32_t N = 0;
@@ -1196,15 +1185,21 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         uint64_t drawn = ~0ull;
         if (S2K_DYNAMIC_TILES && tnn < n_tiles)
             drawn = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)took);
-        issue_next(); // after the hash loop: 40 staging registers live across it would not fit three waves per SIMD
+        // the next tile's loads go out from inside the dense phase, the moment it no longer reads this tile's bytes
+        bool issued = false; // wave-uniform
+        auto issue_once = [&]() {
+            if (!issued) issue_next();
+            issued = true;
+        };
         if (nh != 0 && sem.enabled) {
 #ifndef EXP_NODENSE
             if (!(sem.dbg_skip & 2))
-                N = dense_phase<L, HPC>(S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
+                N = dense_phase<L, HPC>(issue_once, S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
                                      rs0, lane, rec, pool_cursor, mn_cnt, counts, base, sem, caps, raw, ph, stamp);
 #endif
             S2K_STAMP(5); // rounds
         }
+        issue_once();
         if (lane == 0) {
             tile_cnt[t] = N;
             tile_rec_off[t] = base;
