@@ -855,7 +855,10 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     //     No global LOADS in here: a load would make the compiler drain the previous round's stores.
     for (uint32_t b0 = 0; b0 < N; b0 += LISTCAP) {
         wave_sync();
-        { // every lane lists its own hits and stores the kept hash of those that were the last raw hit of their piece
+        // every lane lists its own hits and stores the kept hash of those that were the last raw hit of their piece; a tile
+        // with at most LISTCAP hits (all but low-complexity sequence) takes the instantiation without the batch-range test
+        auto list_hits = [&](auto single_c) {
+            constexpr bool SINGLE = decltype(single_c)::value;
             uint32_t k = myoff;
 #pragma unroll
             for (int d = 0; d < 5; d++) {
@@ -868,14 +871,16 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                     // raw hits after this one inside the same 16-position piece: the kept hash is not this hit's
                     const uint32_t later = rw & ((0xFFFFu << (bit & 16)) & ~((2u << bit) - 1u));
                     const uint32_t hvk = (bit & 16) ? cap_hi : cap_lo;
-                    if (k >= b0 && k < b0 + LISTCAP) {
+                    if (SINGLE || (k >= b0 && k < b0 + LISTCAP)) {
                         S.list[k - b0] = (uint16_t)((Tq * lane + 32 * d + bit) | (later ? 0x8000u : 0u));
                         if (!later && !(sem.dbg_skip & 16)) rec.hash[base + k] = hvk;
                     }
                     k++;
                 }
             }
-        }
+        };
+        if (N <= (uint32_t)LISTCAP) list_hits(std::true_type{});
+        else list_hits(std::false_type{});
         wave_sync();
         S2K_STAMP(4); // scan + list
         const uint32_t bn = N - b0 < (uint32_t)LISTCAP ? N - b0 : (uint32_t)LISTCAP;
