@@ -544,6 +544,11 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     return R;
 }
 
+// x / Tq for a hash position x < 64 Tq, Tq = 16 np, np in {1, 3, 5, 7, 9}: (x >> 4) / np by a 16-bit reciprocal (rcp = 65536 / np + 1:
+// exact while (x >> 4) (rcp np - 65536) < 65536, i.e. for all x < 2^16).  One 24-bit multiply and two shifts instead of the 64-bit
+// multiply-add pair the compiler made of __umulhi with a scalar operand.
+__device__ __forceinline__ uint32_t div_tq(uint32_t x, uint32_t rcp) { return __umul24(x >> 4, rcp) >> 16; }
+
 // Back-map of one Hpc hit: tile-relative raw offsets of run heads x and x + l (x < R; x + l may be one of the
 // run heads that follow the tile).  The owner raw lane of a head is the last o with hbase[o] <= head; S.hl
 // brackets it to the raw lanes spanned by the head's hash lane.  Written so that the LDS reads of the two
@@ -556,7 +561,7 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
     const bool y_in = y < R;
     const uint32_t yy = y_in ? y : x; // look-up 2 degenerates to look-up 1 when x + l lies after the tile
     (void)Tq;
-    const uint32_t q1 = __umulhi(x, rcpTq), q2 = __umulhi(yy, rcpTq);
+    const uint32_t q1 = div_tq(x, rcpTq), q2 = div_tq(yy, rcpTq);
     uint32_t lo1 = S.hl[q1], hi1 = q1 < 63 ? S.hl[q1 + 1] : 63u;
     uint32_t lo2 = S.hl[q2], hi2 = q2 < 63 ? S.hl[q2 + 1] : 63u;
     // three candidates beyond lo at once; a wider bracket (long homopolymers: raw lanes without heads) loops
@@ -613,7 +618,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     //     same read, src/nthash_hpc.rs:265-267).  The first read start at or after the tile end (or the
     //     end of the stream) is the one external boundary.
     const uint32_t wclr = HPC ? (sem.keep_last ? l - 1 : l) : l - 1; // Hpc drops the last l-mer of a read (src/nthash_hpc.rs:265-267)
-    const uint32_t rcpTq = 0xFFFFFFFFu / Tq + 1u; // x / Tq == umulhi(x, rcpTq) for x < 2^16 (Tq <= 144)
+    const uint32_t rcpTq = 65536u / (Tq >> 4) + 1u; // see div_tq
     uint32_t vm[5]; // validated hit mask of this lane
     {
         int vc = (int)nh - (int)(Tq * lane); // hash positions of this lane that exist
@@ -788,7 +793,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                 // lanes left of the boundary's lane count everything, lanes right of it nothing: the total is the
                 // exclusive offset of that lane plus its own share -- one v_readlane instead of a wave scan
                 const int hbi = S.hb[i];
-                const int lb = hbi <= 0 ? 0 : ((uint32_t)hbi >= Tq * 64u ? 63 : (int)__umulhi((uint32_t)hbi, rcpTq));
+                const int lb = hbi <= 0 ? 0 : ((uint32_t)hbi >= Tq * 64u ? 63 : (int)div_tq((uint32_t)hbi, rcpTq));
                 below = bcast(myoff + c, lb);
             }
             if ((uint32_t)lane == i) mine = below - below_prev;
