@@ -9,7 +9,7 @@ pkg = import_package()
 eng = pkg.Engine(0)
 dev = torch.device("cuda", 0)
 
-def run(tag, lens, density, seed):
+def run(tag, lens, density, seed, modes=(pkg.HashMode.Regular, pkg.HashMode.Hpc)):
     off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
     n_reads, n_bases = len(lens), int(off[-1])
     d_b = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
@@ -21,7 +21,7 @@ def run(tag, lens, density, seed):
     o = pkg.DeviceOut(); o.km_capacity = cap
     o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
     torch.cuda.synchronize()
-    for mode in (pkg.HashMode.Regular, pkg.HashMode.Hpc):
+    for mode in modes:
         eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, 31, 10, density, int(mode), o)
         best = 1e9
         for _ in range(3):
@@ -34,3 +34,4 @@ rng = np.random.default_rng(303)
 mu = np.log(20000) - 0.5 * 0.5 / 2
 run("C3-shard (ONT-like, ragged)", np.clip(rng.lognormal(mu, 0.5, size=1_250_000), 1000, 200000).astype(np.int64), 0.01, 3)
 run("C5 (1 Mbp contigs, d=0.001)", np.full(1000, 1_000_000, dtype=np.int64), 0.001, 5)
+run("C2 (1 M x 10 kbp) all four modes", np.full(1_000_000, 10_000, dtype=np.int64), 0.01, 1, modes=(pkg.HashMode.Regular, pkg.HashMode.Hpc, pkg.HashMode.Simd, pkg.HashMode.HpcSimd))
