@@ -331,20 +331,7 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
 // TILE_CURSORS cursors in global memory, two iterations before it processes it; when its cursor runs dry it moves on to
 // one that is not.  (ONE cursor for all waves was measured first: 1.085 M atomics on one address are serialised at ~12 ns
 // each and the kernel took 13.2 ms; 64 addresses, 128 B apart, are not a bottleneck.)
-#ifndef S2K_DYNAMIC_TILES
-#define S2K_DYNAMIC_TILES 1
-#endif
-// s_setprio per phase (0..3; the arbiter prefers higher, then older waves)
-#ifndef S2K_PRIO_STAGE
-#define S2K_PRIO_STAGE 0
-#endif
-#ifndef S2K_PRIO_HASH
-#define S2K_PRIO_HASH 0
-#endif
-#ifndef S2K_PRIO_DENSE
-#define S2K_PRIO_DENSE 0
-#endif
-#define S2K_SETPRIO(p) do { if (S2K_PRIO_STAGE | S2K_PRIO_HASH | S2K_PRIO_DENSE) __builtin_amdgcn_s_setprio(p); } while (0)
+// (s_setprio per phase -- dense phase high and hash loop low, and the reverse -- moved the kernel by <= 1 % either way: not used.)
 
 // Phase stamps (cycles per phase, kept in registers and flushed once per tile to one of 64 shards) exist only in
 // builds with -DS2K_PROFILE (tools/phases.sh): the 16 accumulators cost 32 VGPRs that production kernels need.
@@ -1102,9 +1089,8 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
 
     for (; t < n_tiles;) {
         uint32_t took = 0; // draw for the tile after tnn: issued here, looked at when the pipeline rotates
-        if (S2K_DYNAMIC_TILES && lane == 0 && tnn < n_tiles) took = (uint32_t)atomicAdd(&cursors[16 * cur_g], 1ull);
+        if (lane == 0 && tnn < n_tiles) took = (uint32_t)atomicAdd(&cursors[16 * cur_g], 1ull);
         const uint64_t t0 = t * (uint64_t)TILE_BASES;
-        S2K_SETPRIO(S2K_PRIO_STAGE);
         const uint64_t rem = n_bases - t0;
         const uint32_t avail = rem > (uint64_t)(TILE_BASES + 128) ? (uint32_t)(TILE_BASES + 128) : (uint32_t)rem;
         const uint32_t tile_len = rem > (uint64_t)TILE_BASES ? (uint32_t)TILE_BASES : (uint32_t)rem;
@@ -1182,7 +1168,6 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         if (nh != 0 && sem.enabled) {
             // ---- the hot loop ------------------------------------------------------------------------------
 #ifndef EXP_NOHASH
-            S2K_SETPRIO(S2K_PRIO_HASH);
             if (!(sem.dbg_skip & 1)) hash_stage<L, HPC>(D, tab, sem.bound_le, lane, l, np, caps, raw);
 #endif
             wave_sync();
@@ -1191,9 +1176,8 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         }
         // the draw made at the top of the iteration is looked at HERE: everything older than it in the vector-memory queue had
         // the whole hash loop to finish, whereas at the end of the iteration a wait for it would also drain this tile's stores
-        S2K_SETPRIO(S2K_PRIO_DENSE);
         uint64_t drawn = ~0ull;
-        if (S2K_DYNAMIC_TILES && tnn < n_tiles)
+        if (tnn < n_tiles)
             drawn = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)took);
         // the next tile's loads go out from inside the dense phase, the moment it no longer reads this tile's bytes
         bool issued = false; // wave-uniform
@@ -1218,13 +1202,9 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; // rotate the pipeline
         t = tn;
         tn = tnn;
-        if (S2K_DYNAMIC_TILES) {
-            if (tnn < n_tiles) {
-                tnn = drawn;
-                if (tnn >= n_tiles) tnn = draw_elsewhere();
-            }
-        } else {
-            tnn += n_waves;
+        if (tnn < n_tiles) {
+            tnn = drawn;
+            if (tnn >= n_tiles) tnn = draw_elsewhere();
         }
         S2K_STAMP(6); // tail
     }
