@@ -536,6 +536,42 @@ def test_full_size_config2_whole_run_checksums(eng, oracle):
         assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"]
 
 
+def test_mid_size_every_kernel_instantiation_whole_run_checksums(eng, oracle):
+    """200 Mbp (21 700 tiles: more than the 3 x 3072 a launch deals statically, so the cursors of the dynamic deal are in play)
+    through every instantiation of the tiled kernel -- the unrolled l = 12, 15, 21, 31 and the run-time-l one (l = 25, 64) --
+    in all four modes, whole-run checksums against the oracle."""
+    import os
+    import torch
+
+    n_reads, L, seed = 20_000, 10_000, 7
+    dev = torch.device("cuda", 0)
+    d_b = torch.empty(n_reads * L + 64, dtype=torch.uint8, device=dev)
+    d_o = (torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L)
+    torch.cuda.synchronize()
+    eng.synth_bases_device(seed, 0, n_reads * L, d_b.data_ptr())
+    cap = int(n_reads * L * 0.11)
+    t = {"km_off": torch.empty(n_reads + 1, dtype=torch.int64, device=dev), "hash": torch.empty(cap, dtype=torch.int64, device=dev),
+         "start": torch.empty(cap, dtype=torch.int32, device=dev), "end": torch.empty(cap, dtype=torch.int32, device=dev),
+         "rev": torch.empty(cap, dtype=torch.uint8, device=dev)}
+    o = pkg.DeviceOut()
+    o.km_capacity = cap
+    o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    for l, d in ((12, 0.05), (15, 0.01), (21, 0.02), (25, 0.01), (31, 0.003), (64, 0.01)):
+        for mode in (HM.Regular, HM.Hpc, HM.Simd, HM.HpcSimd):
+            if l > 31 and mode in (HM.Simd, HM.HpcSimd):
+                continue  # the reference's SIMD iterators stop at l = 31
+            torch.cuda.synchronize()
+            c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_reads * L, l, 6, d, int(mode), o)
+            ref = oracle.synth_checksums(seed, n_reads, L, l, 6, d, OMODE[mode], threads=threads)
+            n = c["n_kminmers"]
+            assert c["path"] == 0
+            assert (n, c["n_minimizers"], c["xor_hash"]) == (ref["n_kminmers"], ref["n_minimizers"], ref["xor_hash"]), (l, int(mode), c, ref)
+            assert int(t["start"][:n].to(torch.int64).sum().item()) == ref["sum_start"], (l, int(mode))
+            assert int(t["end"][:n].to(torch.int64).sum().item()) == ref["sum_end"], (l, int(mode))
+            assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"], (l, int(mode))
+
+
 def test_full_size_config3_shard_whole_run_checksums(eng, oracle):
     """BASELINE config 3 at the size ONE GPU holds when 8 share the 200 Gbp: ~25 Gbp of ONT-like reads (lengths
     lognormal, mean 20 kbp, sigma 0.5, clipped to [1 k, 200 k]), l=31 k=10 d=0.01, both scalar modes; every k-min-mer
