@@ -745,7 +745,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     const uint32_t N = bcast(incl, 63); // valid minimizers of this tile
     base = t * rec.slab_cap;
     if (N == 0) {
-        issue_next();
+        issue_next(0u, base);
         return 0;
     }
     if (N > rec.slab_cap) { // rare: more hits than the per-tile slab holds
@@ -759,7 +759,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                 atomicMax((unsigned long long *)&counts->pool_needed, (unsigned long long)(got + N));
             }
             base = 0;
-            issue_next();
+            issue_next(0u, base);
             return 0;
         }
     }
@@ -904,7 +904,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
         }
         if (njobs) flush_jobs();
         S2K_STAMP(12); // hash re-derivation
-        if (b0 + (uint32_t)LISTCAP >= N) issue_next();
+        if (b0 + (uint32_t)LISTCAP >= N) issue_next(N, base);
         auto rounds = [&](auto many_c) {
         constexpr bool MANY = decltype(many_c)::value;
         constexpr int U = 1; // hits per lane per iteration (two overlapped back-maps cost ~25 VGPRs: three waves per SIMD matter more)
@@ -1046,8 +1046,8 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
             if (r < NPRE - 1 || lane < 8)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + 1024 * r),
                                                  (__attribute__((address_space(3))) void *)(dl + 1024 * r), 16, 0, 0);
-        prevb = tt > 0 ? (uint32_t)bases[tt * (uint64_t)TILE_BASES - 1] : 0u;
     };
+    auto byte_before = [&](uint64_t tt) -> uint32_t { return tt > 0 ? (uint32_t)bases[tt * (uint64_t)TILE_BASES - 1] : 0u; };
     auto read_entries = [&](uint32_t rr0, uint64_t &bp, uint64_t &rs) {
         const uint64_t bri = (uint64_t)rr0 + 1 + lane;
         bp = bri <= n_reads ? read_off[bri] : ~0ull; // entry n_reads is the end of the stream
@@ -1056,10 +1056,18 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     uint32_t r0 = tile_read0[t], r1 = tile_read0[t + 1];
     uint64_t bpos0, rs0;
     read_entries(r0, bpos0, rs0);
+    if (is_full(t)) prevb = byte_before(t);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no register load is pending when the loop is entered (see stores_after_dma)
     if (is_full(t)) {
         prefetch(t);
         have_pre = true;
     }
+    // vmcnt is one in-order counter for loads, LDS-DMA loads and stores on gfx9: the wait for a tile's DMA loads at the top of
+    // an iteration would also drain the record stores the rounds issued AFTER them (~2 k cycles per tile, measured as the
+    // "staging" phase).  So the iteration keeps count: nothing but those stores may be issued between the DMA loads and
+    // that wait -- every other load of the next tile's data is issued before the hash loop and waited for right after it --
+    // and the wait leaves exactly that many operations in flight.
+    uint32_t stores_after_dma = 0;
     // tn / tnn: the next two tiles of this wave; >= n_tiles: none.  Dynamic tiles are numbered from dyn0 on: cursor g deals
     // dyn0 + g, dyn0 + g + TILE_CURSORS, ... (pool_cursor[16 + 16 g], zeroed by the host before the launch).
     uint64_t tn = t + n_waves, tnn = t + 2 * n_waves;
@@ -1088,17 +1096,23 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     }
 
     for (; t < n_tiles;) {
-        uint32_t took = 0; // draw for the tile after tnn: issued here, looked at when the pipeline rotates
-        if (lane == 0 && tnn < n_tiles) took = (uint32_t)atomicAdd(&cursors[16 * cur_g], 1ull);
         const uint64_t t0 = t * (uint64_t)TILE_BASES;
         const uint64_t rem = n_bases - t0;
         const uint32_t avail = rem > (uint64_t)(TILE_BASES + 128) ? (uint32_t)(TILE_BASES + 128) : (uint32_t)rem;
         const uint32_t tile_len = rem > (uint64_t)TILE_BASES ? (uint32_t)TILE_BASES : (uint32_t)rem;
         // ---- the tile (+128 B look-ahead) in LDS ------------------------------------------------------------------
         uint32_t l16_tile = 16 * lane;
-        if (have_pre) {
-            // loaded into the buffer by the previous iteration (prologue: just now): wait for the loads, nothing to move
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (__builtin_amdgcn_readfirstlane((int)have_pre)) { // a scalar branch: as a divergent if/else the slow path's loads would precede this wait
+            // loaded into the buffer by the previous iteration (prologue: just now): wait for the loads, nothing to move.
+            // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; 0x0F70 = vmcnt(0) only
+            switch (__builtin_amdgcn_readfirstlane((int)stores_after_dma)) { // wave-uniform, and the compiler should know
+                case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+                case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+                case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break;
+                case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
+                default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+            }
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         } else { // tile at the end of the stream: guarded loads, zero past the end
             const uint8_t *g = bases + t0;
@@ -1118,6 +1132,19 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
             prevb = t0 > 0 ? (uint32_t)bases[t0 - 1] : 0u;
         }
         const uint32_t cr0 = r0, cr1 = r1, cprev = prevb; // this tile's values (the registers get reused below)
+        // ---- loads for the next tiles that land in registers: issued now, waited for right after the hash loop ----------
+        uint32_t took = 0; // draw for the tile after tnn
+        if (lane == 0 && tnn < n_tiles) took = (uint32_t)atomicAdd(&cursors[16 * cur_g], 1ull);
+        uint64_t bposn = ~0ull, rs0n = 0;
+        uint32_t r0nn = 0, r1nn = 0, prevbn = 0;
+        if (tn < n_tiles) {
+            read_entries(r0n, bposn, rs0n);
+            prevbn = byte_before(tn);
+            if (tnn < n_tiles) {
+                r0nn = tile_read0[tnn];
+                r1nn = tile_read0[tnn + 1];
+            }
+        }
         if (lane == 0) S.buf[HS_OFF - 1] = 0;
         if constexpr (HPC) {
 #pragma unroll
@@ -1139,23 +1166,17 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
             np = need <= 1 ? 1 : need <= 3 ? 3 : need <= 5 ? 5 : need <= 7 ? 7 : 9;
         }
         S2K_STAMP(1); // hpc compaction
-        // ---- next tile's loads (see issue_once below) ----------------------------------------------------------------
-        uint64_t bposn = ~0ull, rs0n = 0;
-        uint32_t r0nn = 0, r1nn = 0;
-        auto issue_next = [&]() {
-            have_pre = false;
-            if (tn < n_tiles) {
-                if (is_full(tn)) {
-                    prefetch(tn);
-                    have_pre = true;
-                }
-                read_entries(r0n, bposn, rs0n);
-                if (tnn < n_tiles) {
-                    r0nn = tile_read0[tnn];
-                    r1nn = tile_read0[tnn + 1];
-                }
+        // ---- the next tile's bases: DMA into this wave's buffer, issued from inside the dense phase (see issue_once) -----
+        auto issue_next = [&](uint32_t n_rec, uint64_t rec_base) {
+            if (lane == 0) { // before the DMA loads: only the rounds' stores may follow them
+                tile_cnt[t] = n_rec;
+                tile_rec_off[t] = rec_base;
             }
-            if (!have_pre) prevb = 0;
+            have_pre = false;
+            if (tn < n_tiles && is_full(tn)) {
+                prefetch(tn);
+                have_pre = true;
+            }
         };
         const uint32_t Tq = 16 * np;
         uint32_t N = 0;
@@ -1176,13 +1197,14 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         }
         // the draw made at the top of the iteration is looked at HERE: everything older than it in the vector-memory queue had
         // the whole hash loop to finish, whereas at the end of the iteration a wait for it would also drain this tile's stores
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): everything older had the whole hash loop to finish
         uint64_t drawn = ~0ull;
         if (tnn < n_tiles)
             drawn = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)took);
         // the next tile's loads go out from inside the dense phase, the moment it no longer reads this tile's bytes
         bool issued = false; // wave-uniform
-        auto issue_once = [&]() {
-            if (!issued) issue_next();
+        auto issue_once = [&](uint32_t n_rec, uint64_t rec_base) {
+            if (!issued) issue_next(n_rec, rec_base);
             issued = true;
         };
         if (nh != 0 && sem.enabled) {
@@ -1193,13 +1215,16 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
 #endif
             S2K_STAMP(5); // rounds
         }
-        issue_once();
-        if (lane == 0) {
-            tile_cnt[t] = N;
-            tile_rec_off[t] = base;
+        issue_once(0, 0);
+        // the rounds of the last batch of hits are all that came after the DMA loads: three stores each (the variant for tiles
+        // with very many reads loads and counts in there: it waits for everything)
+        {
+            const bool many = (cr1 - cr0) > (uint32_t)(NBL - 2) || (sem.dbg_skip & 16) != 0; // (KNOBS builds: stores ablated)
+            const uint32_t last = N == 0 ? 0u : N - ((N - 1) / (uint32_t)LISTCAP) * (uint32_t)LISTCAP;
+            stores_after_dma = many ? 0u : 3u * ((last + 63u) / 64u);
         }
         wave_sync(); // LDS of this wave is reused by the next tile
-        r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; // rotate the pipeline
+        r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; prevb = prevbn; // rotate the pipeline
         t = tn;
         tn = tnn;
         if (tnn < n_tiles) {
