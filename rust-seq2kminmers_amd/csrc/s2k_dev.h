@@ -74,7 +74,7 @@ constexpr int XOR_SHARDS = 4096;
 constexpr int TILE_T = 144;              // bases per lane
 constexpr int TILE_BASES = 64 * TILE_T;  // 9216 bases per wave-tile
 // cursors of the tiled kernel's dynamic tile deal (one per lane of a wave that looks for an open one); they follow the
-// overflow-pool cursor in one zeroed array: word 0 = pool cursor, cursor g = word 16 + 16 g (128 B apart)
+// overflow-pool cursor in one zeroed array of 64-bit words: word 0 = pool cursor, cursor g = the low half of word 16 + 16 g (32-bit, 128 B apart)
 constexpr int TILE_CURSORS = 64;
 constexpr int CURSOR_WORDS = 16 + 16 * TILE_CURSORS;
 

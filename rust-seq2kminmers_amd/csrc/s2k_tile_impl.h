@@ -383,6 +383,9 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
             if ((uint64_t)r0 + 1 + c0 + 64 > (uint64_t)r1) break; // wave-uniform: all starts up to r1 covered
             const uint64_t ri = (uint64_t)r0 + 1 + c0 + 64 + lane;
             sp = ri <= n_reads ? read_off[ri] : ~0ull;
+            // (> 63 read starts in a tile: rare.)  Waited for HERE: pending across the back edge, the load would put a vmcnt(0)
+            // at the loop header, i.e. in front of every tile's compaction, and drain the previous tile's stores (see the kernel)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
         }
     }
     wave_sync();
@@ -735,6 +738,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             if (em) break;
             const uint64_t ri = (uint64_t)r0 + 1 + c0 + 64 + lane;
             bpos = ri <= n_reads ? read_off[ri] : ~0ull;
+            __builtin_amdgcn_s_waitcnt(0x0F70); // as in hpc_compact: nothing pending across the back edge
         }
     }
     S2K_STAMP(3); // boundaries
@@ -1038,14 +1042,33 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     uint32_t prevb = 0;
     bool have_pre = false;
     typedef __attribute__((address_space(3))) uint8_t lds_u8s;
+    // The loads are issued from inline asm on purpose.  As compiler-visible LDS-DMA they made LLVM put a vmcnt(0) in front of the
+    // first LDS access of the next tile (it cannot count across the rounds' loop), which also drained the rounds' stores; the
+    // counted wait at the top of the loop is the one that covers them.  Operations the compiler does not know about can only
+    // make ITS counted waits wait longer (vmcnt is in order), never too short.  M0 (LDS base of an LDS-DMA) is saved and restored
+    // inside the statement; the instruction offset moves the global and the LDS address alike (tools/experiments/lds_dma_asm_test.hip).
     auto prefetch = [&](uint64_t tt) { // issue the loads for tile tt; nothing waits here
+        static_assert(NPRE == 10, "4 + 4 + 1 wave-wide loads of 1 KiB and one of 128 B");
         const uint8_t *g = bases + tt * (uint64_t)TILE_BASES + 16 * lane;
-        lds_u8s *dl = (lds_u8s *)D; // wave-uniform: lane i of a load lands at base + 16 i (tools/experiments/lds_direct_test.hip)
+        const uint32_t lbase = (uint32_t)(uintptr_t)(lds_u8s *)D; // wave-uniform: lane i of a load lands at base + offset + 16 i
+        uint32_t save;
 #pragma unroll
-        for (int r = 0; r < NPRE; r++)
-            if (r < NPRE - 1 || lane < 8)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + 1024 * r),
-                                                 (__attribute__((address_space(3))) void *)(dl + 1024 * r), 16, 0, 0);
+        for (int grp = 0; grp < 2; grp++) {
+            const uint8_t *pg = g + 4096 * grp;
+            const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + 4096u * grp));
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(save) : "v"(pg), "s"(m) : "memory");
+        }
+        const uint8_t *pg = g + 8192;
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + 8192u));
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(save) : "v"(pg), "s"(m) : "memory");
+        if (lane < 8) // the 128 B look-ahead
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+                         : "=&s"(save) : "v"(pg), "s"(m) : "memory");
     };
     auto byte_before = [&](uint64_t tt) -> uint32_t { return tt > 0 ? (uint32_t)bases[tt * (uint64_t)TILE_BASES - 1] : 0u; };
     auto read_entries = [&](uint32_t rr0, uint64_t &bp, uint64_t &rs) {
@@ -1073,19 +1096,20 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     uint64_t tn = t + n_waves, tnn = t + 2 * n_waves;
     const uint64_t dyn0 = 3 * n_waves;
     uint32_t cur_g = (uint32_t)((blockIdx.x * TW + w) % TILE_CURSORS);
-    unsigned long long *const cursors = (unsigned long long *)pool_cursor + 16;
+    unsigned int *const cursors = (unsigned int *)(pool_cursor + 16); // 32-bit draws (a 64-bit result's dead upper half would be
+                                                                       // reused early and pull a vmcnt(0) in front of the compaction); cursor g = word 32 g
     // the cursor this wave draws from is dry: look at all of them, move to the next one (cyclically) that is not, draw there
     auto draw_elsewhere = [&]() -> uint64_t {
         for (;;) {
             const uint64_t left_g = dyn0 + (uint64_t)lane < n_tiles ? (n_tiles - dyn0 - lane + TILE_CURSORS - 1) / TILE_CURSORS : 0; // tiles cursor `lane` deals
-            const unsigned long long seen = __hip_atomic_load(&cursors[16 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t seen = __hip_atomic_load(&cursors[32 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint64_t open = __ballot(seen < left_g);
             if (!open) return ~0ull;
             const uint64_t after = open & ~((2ull << cur_g) - 1ull);
             cur_g = (uint32_t)__builtin_ctzll(after ? after : open);
-            unsigned long long got = 0;
-            if (lane == 0) got = atomicAdd(&cursors[16 * cur_g], 1ull);
-            const uint64_t tile = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
+            unsigned int got = 0;
+            if (lane == 0) got = atomicAdd(&cursors[32 * cur_g], 1u);
+            const uint64_t tile = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
             if (tile < n_tiles) return tile;
         }
     };
@@ -1130,16 +1154,21 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
                 *reinterpret_cast<uint4 *>(D + off) = v;
             }
             prevb = t0 > 0 ? (uint32_t)bases[t0 - 1] : 0u;
+            __builtin_amdgcn_s_waitcnt(0x0F70); // inside this branch: pending here, the load would cost the other branch a vmcnt(0) where they meet
         }
         const uint32_t cr0 = r0, cr1 = r1, cprev = prevb; // this tile's values (the registers get reused below)
         // ---- loads for the next tiles that land in registers: issued now, waited for right after the hash loop ----------
         uint32_t took = 0; // draw for the tile after tnn
-        if (lane == 0 && tnn < n_tiles) took = (uint32_t)atomicAdd(&cursors[16 * cur_g], 1ull);
+        if (lane == 0 && tnn < n_tiles) took = atomicAdd(&cursors[32 * cur_g], 1u);
+        // (raw loads at always-valid addresses: the selects that make the final values come after the wait -- a consumer in
+        // here would pull a vmcnt(0) in front of the compaction)
         uint64_t bposn = ~0ull, rs0n = 0;
         uint32_t r0nn = 0, r1nn = 0, prevbn = 0;
+        const uint64_t brin = (uint64_t)r0n + 1 + lane;
         if (tn < n_tiles) {
-            read_entries(r0n, bposn, rs0n);
-            prevbn = byte_before(tn);
+            bposn = read_off[brin <= n_reads ? brin : n_reads];
+            rs0n = read_off[r0n];
+            prevbn = (uint32_t)bases[tn * (uint64_t)TILE_BASES - 1]; // tn > 0
             if (tnn < n_tiles) {
                 r0nn = tile_read0[tnn];
                 r1nn = tile_read0[tnn + 1];
@@ -1198,6 +1227,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         // the draw made at the top of the iteration is looked at HERE: everything older than it in the vector-memory queue had
         // the whole hash loop to finish, whereas at the end of the iteration a wait for it would also drain this tile's stores
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): everything older had the whole hash loop to finish
+        if (brin > n_reads) bposn = ~0ull;  // entry n_reads is the end of the stream, nothing lies beyond it
         uint64_t drawn = ~0ull;
         if (tnn < n_tiles)
             drawn = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)took);
