@@ -1162,16 +1162,21 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         if (lane == 0 && tnn < n_tiles) took = atomicAdd(&cursors[32 * cur_g], 1u);
         // (raw loads at always-valid addresses: the selects that make the final values come after the wait -- a consumer in
         // here would pull a vmcnt(0) in front of the compaction)
+        // The wave-uniform ones are VECTOR loads on purpose (index + an opaque zero in a VGPR): as scalar loads they count in
+        // lgkmcnt, which every wait for this wave's LDS traffic drains -- the two s_load of this block sat right in front of an
+        // s_waitcnt lgkmcnt(0), a full global round trip exposed per tile.
         uint64_t bposn = ~0ull, rs0n = 0;
         uint32_t r0nn = 0, r1nn = 0, prevbn = 0;
         const uint64_t brin = (uint64_t)r0n + 1 + lane;
+        uint32_t vzero = 0;
+        asm volatile("" : "+v"(vzero));
         if (tn < n_tiles) {
             bposn = read_off[brin <= n_reads ? brin : n_reads];
-            rs0n = read_off[r0n];
-            prevbn = (uint32_t)bases[tn * (uint64_t)TILE_BASES - 1]; // tn > 0
+            rs0n = read_off[(uint64_t)r0n + vzero];
+            prevbn = (uint32_t)bases[tn * (uint64_t)TILE_BASES - 1 + vzero]; // tn > 0
             if (tnn < n_tiles) {
-                r0nn = tile_read0[tnn];
-                r1nn = tile_read0[tnn + 1];
+                r0nn = tile_read0[tnn + vzero];
+                r1nn = tile_read0[tnn + 1 + vzero];
             }
         }
         if (lane == 0) S.buf[HS_OFF - 1] = 0;
@@ -1228,6 +1233,11 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         // the whole hash loop to finish, whereas at the end of the iteration a wait for it would also drain this tile's stores
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): everything older had the whole hash loop to finish
         if (brin > n_reads) bposn = ~0ull;  // entry n_reads is the end of the stream, nothing lies beyond it
+        rs0n = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rs0n >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rs0n);
+        r0nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0nn);
+        r1nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)r1nn);
+        prevbn = (uint32_t)__builtin_amdgcn_readfirstlane((int)prevbn);
         uint64_t drawn = ~0ull;
         if (tnn < n_tiles)
             drawn = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)took);
