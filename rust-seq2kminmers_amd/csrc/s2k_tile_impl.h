@@ -420,9 +420,10 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         const uint32_t cur = c[d];
         const uint32_t prv = __builtin_amdgcn_alignbyte(cur, d == 0 ? prevw : c[d - 1], 3); // predecessor of every byte
         const uint32_t x = cur ^ prv;
-        const uint32_t y = ((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u) >> 7; // 1 per byte that differs
-        const uint32_t nib = __builtin_amdgcn_udot4(y, 0x08040201u, 0u, false);
-        fmk[d >> 3] |= nib << (4 * (d & 7));
+        const uint32_t y = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; // 0x80 per byte that differs
+        const uint32_t nib7 = __builtin_amdgcn_udot4(y, 0x08040201u, 0u, false);     // the four flags as a nibble, times 128
+        const int sh = 4 * (d & 7) - 7; // (a constant once the loop is unrolled: one shift per dword)
+        fmk[d >> 3] |= sh >= 0 ? nib7 << (sh >= 0 ? sh : 0) : nib7 >> (sh < 0 ? -sh : 0);
     }
     if (partial) { // only the stream's last tile: bytes past the end are no run heads
 #pragma unroll
