@@ -102,6 +102,10 @@ KERNEL(minxor, A_MINMIN, "memory")
 KERNEL(lshl, A_LSHL, "memory")
 KERNEL(and_, A_AND, "memory")
 KERNEL(sub, A_SUB, "memory")
+#define A_SUBCO(i) "v_sub_co_u32 %8, vcc, %10, %" #i "\n\t"
+KERNEL(subco, A_SUBCO, "vcc")
+#define A_TRACK3(i) "v_sub_co_u32 %8, vcc, %10, %" #i "\n\tv_cndmask_b32 %" #i ", %" #i ", %9, vcc\n\tv_addc_co_u32 %" #i ", vcc, %" #i ", %" #i ", vcc\n\t"
+KERNEL(track3, A_TRACK3, "vcc")
 KERNEL(max, A_MAX, "memory")
 KERNEL(lshl64, A_LSHL64, "v40", "v41")
 KERNEL(madu24, A_MADU24, "memory")
@@ -165,7 +169,7 @@ int main() {
                     {"v_cmp_e64 ->sgpr", k_cmps, 32}, {"v_cndmask_sdwa", k_cndsdwa, 32}, {"min+xor (2)", k_minxor, 64},
                     {"v_lshlrev_b32", k_lshl, 32}, {"v_and_b32", k_and_, 32}, {"v_sub_u32", k_sub, 32}, {"v_max_u32", k_max, 32},
                     {"v_lshlrev_b64", k_lshl64, 32}, {"v_mad_u32_u24", k_madu24, 32}, {"v_bfi_b32", k_bfi, 32},
-                    {"v_xor_b32_sdwa", k_xorsdwa, 32}, {"xor+xor (2)", k_xorxor, 64}};
+                    {"v_xor_b32_sdwa", k_xorsdwa, 32}, {"xor+xor (2)", k_xorxor, 64}, {"v_sub_co_u32", k_subco, 32}, {"sub_co+cnd+addc (3)", k_track3, 96}};
     const int iters = 20000;
     printf("%-22s", "cycles/wave-instr/SIMD");
     for (int wps : {1, 2, 3, 4, 8}) printf("  %dw/SIMD", wps);
