@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the run of the other scalar HashMode")
     ap.add_argument("--cpu-sample-reads", type=int, default=120_000, help="reads of the same workload timed on the CPU")
-    ap.add_argument("--verify-reads", type=int, default=300)
+    ap.add_argument("--verify-reads", type=int, default=2000, help="reads drawn across the whole stream and compared field by field with the oracle (outside the timed region)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: map every rank to GPU 0")
     ap.add_argument("--count", action="store_true", help="also time the downstream k-min-mer count (hash table in HBM; N > 1: all-to-all by hash prefix)")
@@ -240,21 +240,37 @@ def main():
     # ---- verification outside the timed region: a read sample against the oracle ------------------
     verified = None
     if rank == 0 and args.verify_reads > 0:
+        # a sample of reads drawn across the WHOLE stream (first and last reads, and tiles the dynamic deal hands out,
+        # included), regenerated on the host, run through the oracle and compared field by field with the slices
+        # [km_off[r], km_off[r+1]) of the device output
         from oracle import s2k_oracle as so
 
         orc = so.get()
         nv = min(args.verify_reads, n_reads)
-        voff = np.arange(nv + 1, dtype=np.uint64) * args.read_len if host_off is None else host_off[: nv + 1]
-        hb = d_bases[: int(voff[-1])].cpu().numpy()
-        assert (hb[: 4096] == orc.synth_bases(seed, first_base, min(4096, len(hb)))[: len(hb)]).all()
+        ids = set(np.random.default_rng(12345).choice(n_reads, size=nv, replace=False).tolist())
+        ids.update(r for r in (0, 1, n_reads - 2, n_reads - 1) if 0 <= r < n_reads)
+        ids = np.array(sorted(ids), dtype=np.int64)
+        starts = ids.astype(np.uint64) * np.uint64(args.read_len) if host_off is None else host_off[ids]
+        lens = np.full(len(ids), args.read_len, dtype=np.uint64) if host_off is None else host_off[ids + 1] - host_off[ids]
+        voff = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+        hb = np.empty(int(voff[-1]), dtype=np.uint8)
+        for i in range(len(ids)):
+            hb[int(voff[i]): int(voff[i + 1])] = orc.synth_bases(seed, first_base + int(starts[i]), int(lens[i]))
+        a0, n0 = int(starts[0]), int(min(lens[0], 4096))
+        assert (d_bases[a0: a0 + n0].cpu().numpy() == hb[:n0]).all(), "device generator and oracle generator disagree"
         ref = orc.batch(hb, voff, args.l, args.k, args.density, so.HPC if mode == pkg.HashMode.Hpc else so.REGULAR, threads=4)
-        nk = ref["n"]
-        verified = bool((outs["km_off"][: nv + 1].cpu().numpy().view(np.uint64) == ref["km_off"]).all()
-                        and (outs["hash"][:nk].cpu().numpy().view(np.uint64) == ref["hash"]).all()
-                        and (outs["start"][:nk].cpu().numpy().view(np.uint32) == ref["start"]).all()
-                        and (outs["end"][:nk].cpu().numpy().view(np.uint32) == ref["end"]).all()
-                        and (outs["rev"][:nk].cpu().numpy() == ref["rev"]).all())
+        tid = torch.from_numpy(ids).to(dev)
+        s0, s1 = outs["km_off"][tid], outs["km_off"][tid + 1]
+        ln = s1 - s0
+        verified = bool((ln.cpu().numpy().astype(np.uint64) == np.diff(ref["km_off"])).all())
+        if verified and ref["n"]:
+            g = torch.repeat_interleave(s0 - (torch.cumsum(ln, 0) - ln), ln) + torch.arange(ref["n"], dtype=torch.int64, device=dev)
+            verified = bool((outs["hash"][g].cpu().numpy().view(np.uint64) == ref["hash"]).all()
+                            and (outs["start"][g].cpu().numpy().view(np.uint32) == ref["start"]).all()
+                            and (outs["end"][g].cpu().numpy().view(np.uint32) == ref["end"]).all()
+                            and (outs["rev"][g].cpu().numpy() == ref["rev"]).all())
         assert verified, "GPU output differs from the oracle on the verification sample"
+        verified = {"ok": True, "reads": int(len(ids)), "kminmers": int(ref["n"]), "sample": "reads drawn across the whole stream (rng 12345) + first/last"}
     if args.dump_shard:  # tests: concatenating the ranks' dumps must reproduce the unsharded run
         nk = counts["n_kminmers"]
         np.savez(args.dump_shard + ".rank%d.npz" % rank, km_off=outs["km_off"].cpu().numpy().view(np.uint64),

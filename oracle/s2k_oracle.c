@@ -821,15 +821,23 @@ uint64_t s2k_oracle_batch_count_timed(const uint8_t *bases, const uint64_t *off,
 /* ------------------------------------------------------------------------------------------
  * Whole-run checksums of a synthetic batch (n_reads reads of read_len bases cut from the synth_bases stream
  * of `seed`), generated read by read so that BASELINE-size runs (10 Gbp) need no 10 GB host buffer.
- * out = { n_minimizers, n_kminmers, XOR hash, SUM start, SUM end, #rev }.
+ * out = { n_minimizers, n_kminmers, XOR hash, SUM start, SUM end, #rev,
+ *         FOLD hash, FOLD start, FOLD end, FOLD rev, FOLD km_off, FOLD per-read count } where
+ *   FOLD x      = SUM_g x[g] * (2 g + 1) mod 2^64, g = index of the item in the whole output (reads in order),
+ *   FOLD km_off = SUM_r km_off[r] * (2 r + 1) mod 2^64 over r = 0 .. n_reads (the end entry included).
+ * XOR / SUM do not see a permutation of the items; the folds do (two tiles' outputs swapped, a wrong km_off,
+ * one read's items in another's place all change them).
  * ---------------------------------------------------------------------------------------- */
+#define S2K_NSUM 12
 struct sum_job {
     const uint64_t *off; /* NULL: reads of read_len bases each; else read r = stream [off[r], off[r+1]) */
     uint64_t seed, r0, r1, read_len;
     unsigned l, k;
     uint32_t bound;
     int mode;
-    uint64_t out[6];
+    uint64_t out[S2K_NSUM];
+    /* thread-local pieces of the folds: items are numbered from 0 inside the thread's read range, the combiner adds the base */
+    uint64_t sum_hash; /* SUM hash (mod 2^64) */
 };
 
 static void *sum_worker(void *p) {
@@ -848,34 +856,43 @@ static void *sum_worker(void *p) {
         s2k_oracle_synth_bases(jb->seed, a, n, buf);
         size_t M = s2k_oracle_minimizers(buf, n, jb->l, jb->bound, jb->mode, NULL, NULL, NULL, 0);
         size_t c = kminmers_one(buf, n, jb->l, jb->k, jb->bound, jb->mode, h, st, en, rv, ocap, &scratch, &scap);
+        /* km_off of this read, counted from the thread's first read */
+        jb->out[10] += jb->out[1] * (2 * r + 1);
+        jb->out[11] += (uint64_t)c * (2 * r + 1);
         jb->out[0] += M;
-        jb->out[1] += c;
         for (size_t i = 0; i < c; i++) {
+            const uint64_t w = 2 * (jb->out[1] + i) + 1; /* local item index */
             jb->out[2] ^= h[i];
             jb->out[3] += st[i];
             jb->out[4] += en[i];
             jb->out[5] += rv[i];
+            jb->sum_hash += h[i];
+            jb->out[6] += h[i] * w;
+            jb->out[7] += st[i] * w;
+            jb->out[8] += en[i] * w;
+            jb->out[9] += (uint64_t)rv[i] * w;
         }
+        jb->out[1] += c;
     }
     free(buf); free(h); free(st); free(en); free(rv); free(scratch);
     return NULL;
 }
 
 static void synth_checksums_impl(uint64_t seed, const uint64_t *off, uint64_t n_reads, uint64_t read_len, unsigned l,
-                                 unsigned k, double density, int mode, int threads, uint64_t out[6]);
+                                 unsigned k, double density, int mode, int threads, uint64_t out[S2K_NSUM]);
 
 void s2k_oracle_synth_checksums(uint64_t seed, uint64_t n_reads, uint64_t read_len, unsigned l, unsigned k,
-                                double density, int mode, int threads, uint64_t out[6]) {
+                                double density, int mode, int threads, uint64_t out[S2K_NSUM]) {
     synth_checksums_impl(seed, NULL, n_reads, read_len, l, k, density, mode, threads, out);
 }
 
 void s2k_oracle_synth_checksums_off(uint64_t seed, const uint64_t *off, uint64_t n_reads, unsigned l, unsigned k,
-                                    double density, int mode, int threads, uint64_t out[6]) {
+                                    double density, int mode, int threads, uint64_t out[S2K_NSUM]) {
     synth_checksums_impl(seed, off, n_reads, 0, l, k, density, mode, threads, out);
 }
 
 static void synth_checksums_impl(uint64_t seed, const uint64_t *off, uint64_t n_reads, uint64_t read_len, unsigned l,
-                                 unsigned k, double density, int mode, int threads, uint64_t out[6]) {
+                                 unsigned k, double density, int mode, int threads, uint64_t out[S2K_NSUM]) {
     tables();
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > n_reads) threads = n_reads ? (int)n_reads : 1;
@@ -893,14 +910,25 @@ static void synth_checksums_impl(uint64_t seed, const uint64_t *off, uint64_t n_
         jobs[t].mode = mode;
         pthread_create(&th[t], NULL, sum_worker, &jobs[t]);
     }
-    memset(out, 0, 6 * sizeof(uint64_t));
-    for (int t = 0; t < threads; t++) {
-        pthread_join(th[t], NULL);
-        out[0] += jobs[t].out[0];
-        out[1] += jobs[t].out[1];
-        out[2] ^= jobs[t].out[2];
-        for (int i = 3; i < 6; i++) out[i] += jobs[t].out[i];
+    memset(out, 0, S2K_NSUM * sizeof(uint64_t));
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    for (int t = 0; t < threads; t++) { /* in read order: out[1] is the number of items before this thread's first one */
+        const struct sum_job *jb = &jobs[t];
+        const uint64_t g0 = out[1];
+        /* SUM x (2 (g0 + i) + 1) = SUM x (2 i + 1) + 2 g0 SUM x */
+        out[6] += jb->out[6] + 2 * g0 * jb->sum_hash;
+        out[7] += jb->out[7] + 2 * g0 * jb->out[3];
+        out[8] += jb->out[8] + 2 * g0 * jb->out[4];
+        out[9] += jb->out[9] + 2 * g0 * jb->out[5];
+        /* SUM_r (g0 + local_off[r]) (2 r + 1), SUM_{r0 <= r < r1} (2 r + 1) = r1^2 - r0^2 */
+        out[10] += jb->out[10] + g0 * (jb->r1 * jb->r1 - jb->r0 * jb->r0);
+        out[11] += jb->out[11];
+        out[0] += jb->out[0];
+        out[1] += jb->out[1];
+        out[2] ^= jb->out[2];
+        for (int i = 3; i < 6; i++) out[i] += jb->out[i];
     }
+    out[10] += out[1] * (2 * n_reads + 1); /* the end entry km_off[n_reads] */
     free(jobs);
     free(th);
 }

@@ -100,13 +100,15 @@ uint64_t s2k_oracle_batch_minimizers(const uint8_t *bases, const uint64_t *off, 
 void s2k_oracle_synth_bases(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *out);
 
 /* Whole-run checksums of n_reads synthetic reads of read_len bases (read r = synth stream [r*read_len, (r+1)*read_len)),
- * generated on the fly: out = { n_minimizers, n_kminmers, XOR hash, SUM start, SUM end, #rev }. */
+ * generated on the fly: out = { n_minimizers, n_kminmers, XOR hash, SUM start, SUM end, #rev, FOLD hash, FOLD start,
+ * FOLD end, FOLD rev, FOLD km_off, FOLD per-read count }, FOLD x = SUM_g x[g] (2 g + 1) mod 2^64 over the global item
+ * index g (order-sensitive), FOLD km_off = SUM_r km_off[r] (2 r + 1) over r = 0 .. n_reads. */
 void s2k_oracle_synth_checksums(uint64_t seed, uint64_t n_reads, uint64_t read_len, unsigned l, unsigned k,
-                                double density, int mode, int threads, uint64_t out[6]);
+                                double density, int mode, int threads, uint64_t out[12]);
 
 /* Same for ragged reads: read r = synth stream [off[r], off[r+1]). */
 void s2k_oracle_synth_checksums_off(uint64_t seed, const uint64_t *off, uint64_t n_reads, unsigned l, unsigned k,
-                                    double density, int mode, int threads, uint64_t out[6]);
+                                    double density, int mode, int threads, uint64_t out[12]);
 
 #ifdef __cplusplus
 }

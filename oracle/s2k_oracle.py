@@ -11,6 +11,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REGULAR, HPC, SIMD, HPCSIMD = 0, 1, 2, 3
 
+# whole-run checksums (s2k_oracle_synth_checksums): the fold_* ones are order-sensitive, SUM x[g] (2 g + 1) mod 2^64
+CHECKSUM_FIELDS = ("n_minimizers", "n_kminmers", "xor_hash", "sum_start", "sum_end", "n_rev",
+                   "fold_hash", "fold_start", "fold_end", "fold_rev", "fold_km_off", "fold_count")
+
 _u8p = C.POINTER(C.c_uint8)
 _u32p = C.POINTER(C.c_uint32)
 _u64p = C.POINTER(C.c_uint64)
@@ -215,16 +219,16 @@ class Oracle:
 
     def synth_checksums(self, seed, n_reads, read_len, l, k, density, mode, threads=1):
         """whole-run checksums of a synthetic batch generated read by read (no big host buffer)"""
-        out = np.zeros(6, dtype=np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
         self.lib.s2k_oracle_synth_checksums(seed, n_reads, read_len, l, k, density, mode, threads, _ptr(out, _u64p))
-        return dict(zip(("n_minimizers", "n_kminmers", "xor_hash", "sum_start", "sum_end", "n_rev"), map(int, out)))
+        return dict(zip(CHECKSUM_FIELDS, map(int, out)))
 
     def synth_checksums_off(self, seed, off, l, k, density, mode, threads=1):
         """as synth_checksums for ragged reads: read r = synthetic stream [off[r], off[r+1])"""
         off = np.ascontiguousarray(off, dtype=np.uint64)
-        out = np.zeros(6, dtype=np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
         self.lib.s2k_oracle_synth_checksums_off(seed, _ptr(off, _u64p), len(off) - 1, l, k, density, mode, threads, _ptr(out, _u64p))
-        return dict(zip(("n_minimizers", "n_kminmers", "xor_hash", "sum_start", "sum_end", "n_rev"), map(int, out)))
+        return dict(zip(CHECKSUM_FIELDS, map(int, out)))
 
     def batch_minimizers(self, bases, off, l, density, mode):
         bases = self._seq(bases)

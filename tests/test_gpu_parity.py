@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLD
-from gpu_util import FIELDS, OMODE, compare, pkg, rand_read
+from gpu_util import FIELDS, FOLD_FIELDS, OMODE, compare, folds_torch, pkg, rand_read, sample_reads_compare, spread_sample
 
 pytestmark = pytest.mark.gpu
 HM = pkg.HashMode
@@ -534,6 +534,13 @@ def test_full_size_config2_whole_run_checksums(eng, oracle):
         assert int(t["start"][:n].to(torch.int64).sum().item()) == ref["sum_start"]
         assert int(t["end"][:n].to(torch.int64).sum().item()) == ref["sum_end"]
         assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"]
+        # order-sensitive: position-weighted folds over the global item index, and over km_off
+        assert folds_torch(t, n, n_reads) == {x: ref[x] for x in FOLD_FIELDS}, int(mode)
+        # >= 1 % of the reads element by element, drawn across the whole stream (the last tile and tiles
+        # beyond the 3 x 3072 statically dealt ones included)
+        ids = spread_sample(n_reads, 0.0105, np.random.default_rng(1000 + int(mode)), must=(921, 922, 9215, 9216, n_reads // 2))
+        assert len(ids) >= n_reads // 100
+        assert sample_reads_compare(t, n, oracle, seed, 0, lambda r: (r * L, L), ids, 31, 10, 0.01, OMODE[mode], threads=threads) > 0
 
 
 def test_mid_size_every_kernel_instantiation_whole_run_checksums(eng, oracle):
@@ -570,6 +577,7 @@ def test_mid_size_every_kernel_instantiation_whole_run_checksums(eng, oracle):
             assert int(t["start"][:n].to(torch.int64).sum().item()) == ref["sum_start"], (l, int(mode))
             assert int(t["end"][:n].to(torch.int64).sum().item()) == ref["sum_end"], (l, int(mode))
             assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"], (l, int(mode))
+            assert folds_torch(t, n, n_reads) == {x: ref[x] for x in FOLD_FIELDS}, (l, int(mode))
 
 
 def test_full_size_config3_shard_whole_run_checksums(eng, oracle):
@@ -607,6 +615,11 @@ def test_full_size_config3_shard_whole_run_checksums(eng, oracle):
         assert int(t["start"][:n].to(torch.int64).sum().item()) == ref["sum_start"]
         assert int(t["end"][:n].to(torch.int64).sum().item()) == ref["sum_end"]
         assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"]
+        assert folds_torch(t, n, n_reads) == {x: ref[x] for x in FOLD_FIELDS}, int(mode)
+        ids = spread_sample(n_reads, 0.0105, np.random.default_rng(3000 + int(mode)))
+        assert len(ids) >= n_reads // 100
+        assert sample_reads_compare(t, n, oracle, 3, 0, lambda r: (int(off[r]), int(lens[r])), ids, 31, 10, 0.01, OMODE[mode],
+                                    threads=threads) > 0
     del d_b, t
     torch.cuda.empty_cache()
 
@@ -686,6 +699,9 @@ def test_full_size_config5_whole_run_checksums(eng, oracle):
         assert int(t["start"][:n].to(torch.int64).sum().item()) == ref["sum_start"]
         assert int(t["end"][:n].to(torch.int64).sum().item()) == ref["sum_end"]
         assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"]
+        assert folds_torch(t, n, n_reads) == {x: ref[x] for x in FOLD_FIELDS}, int(mode)
+        ids = spread_sample(n_reads, 0.02, np.random.default_rng(5000 + int(mode)))
+        assert sample_reads_compare(t, n, oracle, seed, 0, lambda r: (r * L, L), ids, 31, 10, 0.001, OMODE[mode], threads=threads) > 0
 
 
 def test_degenerate_batches(eng, oracle):

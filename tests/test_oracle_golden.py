@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLD
+from gpu_util import FOLD_FIELDS, folds_np
 from oracle import s2k_oracle as so
 
 KAT = json.load(open(os.path.join(GOLD, "ref_kat.json")))
@@ -234,6 +235,8 @@ def test_synth_checksums_equal_materialised_batch(oracle):
         assert cs["sum_end"] == int(ref["end"].astype(np.uint64).sum())
         assert cs["n_rev"] == int(ref["rev"].sum())
         assert cs["n_minimizers"] == int(oracle.batch_minimizers(bases, off, 31, 0.01, mode)["n"])
+        f = folds_np(ref["km_off"], ref["hash"], ref["start"], ref["end"], ref["rev"])
+        assert {x: cs[x] for x in FOLD_FIELDS} == f
 
 
 def test_synth_checksums_ragged_equal_materialised_batch(oracle):
