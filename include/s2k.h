@@ -30,13 +30,18 @@
 extern "C" {
 #endif
 
-#define S2K_ABI_VERSION 1
+/* ABI history.  1: round-1 surface.  2: + s2k_set_host_batch, s2k_hpc_device_ex, s2k_count_device, s2k_partition_device,
+ * S2K_FLAG_NO_PACK2; s2k_extract sends 2-bit packed bases and pipelines sub-batches by default; the arrays of an s2k_result
+ * are NULL when their count is 0; device-resident read tables are validated on the device (S2K_ERR_INVALID_ARG /
+ * S2K_ERR_READ_TOO_LONG from s2k_extract_device, s2k_sync and s2k_hpc_device*); S2K_ERR_NON_ASCII is no longer returned.
+ * A binding must refuse a library whose s2k_abi_version() differs from the header it was built against. */
+#define S2K_ABI_VERSION 2
 
 typedef struct s2k_ctx s2k_ctx; /* opaque; cf. nthashc_create/destroy, src/nthash_c.rs:14-29 */
 
 typedef enum s2k_status {
     S2K_OK = 0,
-    S2K_ERR_INVALID_ARG = 1,   /* NULL pointer, non-monotone read_off, unknown mode */
+    S2K_ERR_INVALID_ARG = 1,   /* NULL pointer, unknown mode, a read table that does not start at 0 / is not non-decreasing / does not end at n_bases */
     S2K_ERR_L_RANGE = 2,       /* l == 0 or l >= 256 (src/nthash_hpc.rs:123-125,133); Simd modes: l > 31 (src/nthash_avx512_32.rs:33) */
     S2K_ERR_K_RANGE = 3,       /* k == 0 (src/lib.rs:246 would underflow) or k > 4096 */
     S2K_ERR_READ_TOO_LONG = 4, /* a read longer than 2^32-2 bases (positions are u32, cf. src/nthash_hpc_simd.rs:26) */
@@ -44,7 +49,7 @@ typedef enum s2k_status {
     S2K_ERR_NOMEM = 6,
     S2K_ERR_CAPACITY = 7,      /* caller-provided device output too small; counts say what is needed */
     S2K_ERR_NO_DEVICE = 8,     /* no gfx950 device visible: there is NO CPU fallback */
-    S2K_ERR_NON_ASCII = 9      /* a base >= 0x80 met by the tiled kernels in a mode that cannot take it; see s2k_extract */
+    S2K_ERR_NON_ASCII = 9      /* reserved: returned by ABI 1 for bytes >= 0x80 in Hpc mode; every byte value is accepted now */
 } s2k_status;
 
 /* HashMode, src/lib.rs:21-27 */
@@ -80,7 +85,8 @@ typedef struct s2k_counts {
 } s2k_counts;
 
 /* Host-side result, SoA.  Item i of read r (km_off[r] <= i < km_off[r+1]) is
- * KminmerHash{ hash[i], start[i], end[i], offset = i - km_off[r], rev[i] }  (src/kminmer.rs:128-135). */
+ * KminmerHash{ hash[i], start[i], end[i], offset = i - km_off[r], rev[i] }  (src/kminmer.rs:128-135).
+ * hash / start / end / rev are NULL when n_kminmers == 0, the mn_* arrays when n_minimizers == 0. */
 typedef struct s2k_result {
     uint64_t n_reads;
     uint64_t n_kminmers;
@@ -135,14 +141,24 @@ uint32_t s2k_hash_bound(double density);
 /* ---- the hot path ---------------------------------------------------------------------------- */
 /* Replaces: for each read r { KminmersIterator::new(&bases[read_off[r]..read_off[r+1]], l, k, density,
  * mode)?.collect() } -- src/lib.rs:89,179 driven by src/main.rs:65-79.  Host buffers in, host SoA out
- * (library-owned; release with s2k_result_free).  Reads with len <= l yield nothing (src/lib.rs:97). */
+ * (library-owned; release with s2k_result_free).  Reads with len <= l yield nothing (src/lib.rs:97).
+ * s2k_result_free hands the arrays back to a pool kept by the context that made them (fresh gigabyte allocations cost
+ * more in page faults than the copy): a long-lived context retains the arrays of up to two freed results (18 blocks, sized
+ * by the largest recent call) of host memory until s2k_trim() or s2k_destroy(). */
 s2k_status s2k_extract(s2k_ctx *ctx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
                        const s2k_params *params, s2k_result *out);
 void s2k_result_free(s2k_result *res);
 
-/* Same computation with inputs and outputs resident in HBM: d_read_off[0] must be 0 and d_read_off[n_reads] ==
- * n_bases (read r = d_bases[d_read_off[r] .. d_read_off[r+1])); a d_bases pointer that is not 16-byte aligned is
- * accepted but takes the slower read-serial kernels.  Enqueued on the context's stream; if
+/* Releases what a context keeps between calls: idle host result blocks and the device workspace (both grow again on
+ * demand).  Call it when a long-lived context has seen an unusually large batch. */
+s2k_status s2k_trim(s2k_ctx *ctx);
+
+/* Same computation with inputs and outputs resident in HBM: d_read_off[0] must be 0, the table non-decreasing and
+ * d_read_off[n_reads] == n_bases (read r = d_bases[d_read_off[r] .. d_read_off[r+1])) -- checked on the device: a table
+ * that breaks this yields S2K_ERR_INVALID_ARG (a read longer than 2^32-2 bases S2K_ERR_READ_TOO_LONG) from this call
+ * or, with counts == NULL, from s2k_sync(), and nothing is computed.  A d_bases pointer that is not 16-byte aligned is
+ * accepted: the stream is first copied to an aligned buffer (one device-to-device pass) and takes the same tiled
+ * kernels.  Enqueued on the context's stream; if
  * `counts` is non-NULL the call waits for completion and fills it (and returns S2K_ERR_CAPACITY if
  * an output capacity was too small -- counts then hold the required sizes).  With counts == NULL the
  * call returns after enqueueing; s2k_sync() later waits and reports the same status/counts. */

@@ -21,8 +21,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libs2k.so")
 
+ABI_VERSION = 2  # include/s2k.h S2K_ABI_VERSION this mirror was written against
+
 ABI_SYMBOLS = [
-    "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_set_host_batch", "s2k_strerror",
+    "s2k_trim", "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_set_host_batch", "s2k_strerror",
     "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
     "s2k_hpc_device", "s2k_hpc_device_ex", "s2k_count_device", "s2k_partition_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
 ]
@@ -94,6 +96,9 @@ def load_library(path=None):
         raise ImportError("%s is missing: build it with `make -C %s` (or __graft_entry__.build())" % (p, os.path.dirname(p)))
     L = C.CDLL(p)
     L.s2k_abi_version.restype = C.c_int
+    if L.s2k_abi_version() != ABI_VERSION:
+        raise ImportError("%s has ABI version %d, this binding needs %d: rebuild it (make -C %s)" % (p, L.s2k_abi_version(), ABI_VERSION, os.path.dirname(p)))
+    L.s2k_trim.argtypes = [C.c_void_p]
     L.s2k_device_count.restype = C.c_int
     L.s2k_create.restype = C.c_void_p
     L.s2k_create.argtypes = [C.c_int, C.POINTER(C.c_int)]
@@ -192,6 +197,10 @@ class Engine:
     def set_host_batch(self, bases):
         """Bases per sub-batch of `extract` (host buffers): H2D / kernels / D2H of consecutive sub-batches overlap."""
         self._check(self.lib.s2k_set_host_batch(self.ctx, int(bases)))
+
+    def trim(self):
+        """release what the context keeps between calls (idle host result blocks, device workspace)"""
+        self._check(self.lib.s2k_trim(self.ctx))
 
     def enable_timing(self, on=True):
         self._check(self.lib.s2k_enable_timing(self.ctx, 1 if on else 0))

@@ -80,6 +80,19 @@ struct HostPool {
         }
         free(drop);
     }
+    size_t trim() { // s2k_trim: give every idle block back to the allocator
+        std::vector<Blk> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            drop.swap(idle);
+        }
+        size_t bytes = 0;
+        for (Blk &b : drop) {
+            bytes += b.cap;
+            free(b.p);
+        }
+        return bytes;
+    }
     ~HostPool() {
         for (Blk &b : idle) free(b.p);
     }
@@ -155,6 +168,7 @@ struct s2k_ctx {
     bool own_stream = false;
     DevBuf ws, in_bases, in_off, outbuf, realign; // realign: aligned copy of a caller's misaligned device stream
     DevBuf in_bases2, in_off2, outbuf2;           // second set: s2k_extract double-buffers its sub-batches
+    DevBuf count_tab;                             // s2k_count_device: the hash table (grow-only, like ws)
     hipStream_t s_in = nullptr, s_out = nullptr;  // s2k_extract: H2D of the next / D2H of the previous sub-batch
     uint64_t host_batch = 1ull << 29;             // bases per sub-batch of s2k_extract (s2k_set_host_batch)
     Counts *d_counts = nullptr;
@@ -179,6 +193,7 @@ HostStager &ctx_stager(s2k_ctx *c) { return c->stager; }
 hipStream_t ctx_stream(s2k_ctx *c) { return c->stream; }
 int ctx_device(s2k_ctx *c) { return c->device; }
 void ctx_set_error(s2k_ctx *c, const char *what) { c->err = what; }
+void *ctx_count_table(s2k_ctx *c, size_t bytes) { return c->count_tab.ensure(bytes) == hipSuccess ? c->count_tab.p : nullptr; }
 } // namespace s2k
 
 namespace {
@@ -358,12 +373,15 @@ s2k_status enqueue(s2k_ctx *ctx) {
     S2K_TRY(hipMemsetAsync(ctx->d_counts, 0, sizeof(Counts), st), "memset counts");
     S2K_TRY(hipMemsetAsync(ctx->d_xor, 0, XOR_SHARDS * sizeof(uint64_t), st), "memset xor");
     S2K_TRY(hipMemsetAsync(pool_cursor, 0, CURSOR_WORDS * sizeof(uint64_t), st), "memset cursors");
+    // the read table is caller memory in HBM: checked on the device, first thing in the stream; the kernels below look at
+    // the verdict (or clamp what they read from the table) and the host reports it in finish()
+    S2K_TRY(launch_validate_read_off(c.d_read_off, n_reads, n_bases, &ctx->d_counts->bad_input, st), "read table validation");
 
     if (c.serial) {
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
-        S2K_TRY(launch_serial_count(c.d_bases, c.d_read_off, n_reads, c.sem, mn_cnt, st), "serial count kernel");
+        S2K_TRY(launch_serial_count(c.d_bases, c.d_read_off, n_reads, n_bases, c.sem, mn_cnt, st), "serial count kernel");
         S2K_TRY(launch_scan_u32(mn_cnt, n_reads, mn_off, scan_tmp, 0, st), "scan");
-        S2K_TRY(launch_serial_write(c.d_bases, c.d_read_off, n_reads, c.sem, mn_off, rec, ctx->d_counts, st), "serial write kernel");
+        S2K_TRY(launch_serial_write(c.d_bases, c.d_read_off, n_reads, n_bases, c.sem, mn_off, rec, ctx->d_counts, st), "serial write kernel");
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
     } else {
         S2K_TRY(hipMemsetAsync(mn_cnt, 0, (n_reads + 1) * sizeof(uint32_t), st), "memset mn_cnt");
@@ -408,12 +426,14 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
         ctx->pending = false;
         Counts *h = ctx->h_counts;
         Call &c = ctx->call;
-        if (!c.serial && h->non_ascii) { // tiled kernels met a byte >= 0x80 in Hpc mode: exact fallback
-            c.serial = true;
-            c.pool_cap = pool_estimate(c.n_bases, c.n_reads, c.params.density, c.sem.hpc);
-            s2k_status st = enqueue(ctx);
-            if (st != S2K_OK) return st;
-            continue;
+        if (h->bad_input) { // the device-resident read table failed validate_read_off_kernel: nothing was computed
+            ctx->pending_status = (h->bad_input & ~(uint32_t)BAD_LONG) ? S2K_ERR_INVALID_ARG : S2K_ERR_READ_TOO_LONG;
+            ctx->err = (h->bad_input & BAD_FIRST)   ? "d_read_off[0] != 0"
+                       : (h->bad_input & BAD_ORDER) ? "d_read_off is not non-decreasing"
+                       : (h->bad_input & BAD_END)   ? "d_read_off[n_reads] != n_bases"
+                                                    : "a read is longer than 2^32-2 bases";
+            c.valid = false;
+            return ctx->pending_status;
         }
         if (h->pool_overflow) { // record pool (serial) / overflow region (tiled) too small: re-run with the exact size
             c.pool_cap = h->pool_needed + h->pool_needed / 64 + (uint64_t)TILE_BASES + 4096;
@@ -479,7 +499,7 @@ const char *s2k_strerror(s2k_status st) {
     case S2K_ERR_NOMEM: return "out of memory";
     case S2K_ERR_CAPACITY: return "device output capacity too small";
     case S2K_ERR_NO_DEVICE: return "no GPU visible (this library has no CPU path)";
-    case S2K_ERR_NON_ASCII: return "input holds bytes >= 0x80";
+    case S2K_ERR_NON_ASCII: return "reserved (not returned since ABI 2: every byte value is accepted)";
     }
     return "unknown status";
 }
@@ -537,6 +557,7 @@ void s2k_destroy(s2k_ctx *ctx) {
     ctx->in_bases2.release();
     ctx->in_off2.release();
     ctx->outbuf2.release();
+    ctx->count_tab.release();
     if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
     if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -638,6 +659,20 @@ s2k_status s2k_extract_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64
     st = enqueue(ctx);
     if (st != S2K_OK) return st;
     if (counts) return finish(ctx, counts);
+    return S2K_OK;
+}
+
+s2k_status s2k_trim(s2k_ctx *ctx) {
+    if (!ctx) return S2K_ERR_INVALID_ARG;
+    if (ctx->pending) {
+        s2k_status st = finish(ctx, nullptr);
+        if (st != S2K_OK && st != S2K_ERR_CAPACITY) return st;
+    }
+    (void)ctx->host_pool->trim();
+    S2K_TRY(hipSetDevice(ctx->device), "set device");
+    S2K_TRY(hipStreamSynchronize(ctx->stream), "stream synchronize");
+    for (DevBuf *b : {&ctx->ws, &ctx->in_bases, &ctx->in_off, &ctx->outbuf, &ctx->realign, &ctx->in_bases2, &ctx->in_off2, &ctx->outbuf2, &ctx->count_tab})
+        b->release();
     return S2K_OK;
 }
 
@@ -1023,6 +1058,15 @@ s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_
         S2K_TRY(ctx->realign.ensure(n_bases + 256), "aligned copy of a misaligned input stream");
         S2K_TRY(hipMemcpyAsync(ctx->realign.p, d_bases, n_bases, hipMemcpyDeviceToDevice, ctx->stream), "realign copy");
         d_bases = (const uint8_t *)ctx->realign.p;
+    }
+    { // the read table is caller memory in HBM: checked on the device before any kernel walks it (this call blocks anyway)
+        S2K_TRY(hipMemsetAsync(&ctx->d_counts->bad_input, 0, sizeof(uint32_t), ctx->stream), "memset");
+        S2K_TRY(launch_validate_read_off(d_read_off, n_reads, n_bases, &ctx->d_counts->bad_input, ctx->stream), "read table validation");
+        uint32_t bad = 0;
+        S2K_TRY(hipMemcpyAsync(&bad, &ctx->d_counts->bad_input, sizeof bad, hipMemcpyDeviceToHost, ctx->stream), "D2H");
+        S2K_TRY(hipStreamSynchronize(ctx->stream), "stream synchronize");
+        if (bad & ~(uint32_t)BAD_LONG) return fail(ctx, S2K_ERR_INVALID_ARG, "d_read_off must start at 0, be non-decreasing and end at n_bases");
+        if (bad) return fail(ctx, S2K_ERR_READ_TOO_LONG, "a read is longer than 2^32-2 bases");
     }
     const bool seg_path = n_reads && n_bases && ((uintptr_t)d_bases & 15) == 0;
     const uint64_t nblk = n_bases / 256 + 1;

@@ -5,8 +5,10 @@
 // the oracle's hashes (tests/test_count.py).
 //
 // Two device ops, both hand-written (no rocPRIM):
-//  * s2k_count_device: open-addressing table in HBM (linear probing on a power-of-two table of >= 2n slots, 64-bit
-//    atomicCAS for the key, 32-bit atomicAdd for the count), then an unordered compaction of the occupied slots.
+//  * s2k_count_device: open-addressing table in HBM (linear probing on a table of 1.5 n slots -- any size: the first slot
+//    is mulhi(mixed key, slots) -- 64-bit atomicCAS for the key, 32-bit atomicAdd for the count), then an unordered
+//    compaction of the occupied slots.  The table lives in a grow-only buffer of the context (no hipMalloc / hipFree,
+//    i.e. no device-wide synchronisation, per call).
 //  * s2k_partition_device: split the keys into n_parts ranges of the hash space (part = mulhi(hash, n_parts), i.e. by
 //    hash PREFIX) -- the send buffers of the one real exchange step of the multi-GPU version: an all-to-all after which
 //    rank p owns every occurrence of the hashes in its range and counts locally (rust-seq2kminmers_amd/sharding.py).
@@ -26,21 +28,21 @@ __device__ inline uint64_t slot_hash(uint64_t k) { // the keys are hashes alread
 }
 
 __global__ __launch_bounds__(256) void count_insert_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint64_t *tkeys,
-                                                           uint32_t *tcnt, uint64_t mask, uint32_t *n_empty_key) {
+                                                           uint32_t *tcnt, uint64_t slots, uint32_t *n_empty_key) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t k = keys[i];
         if (k == EMPTY) {
             atomicAdd(n_empty_key, 1u);
             continue;
         }
-        uint64_t s = slot_hash(k) & mask;
-        for (uint64_t probe = 0; probe <= mask; probe++) { // the table has >= 2n slots: terminates long before
+        uint64_t s = __umul64hi(slot_hash(k), slots);
+        for (uint64_t probe = 0; probe < slots; probe++) { // the table has >= 1.5 n slots: terminates long before
             const uint64_t prev = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY, (unsigned long long)k);
             if (prev == EMPTY || prev == k) {
                 atomicAdd(&tcnt[s], 1u);
                 break;
             }
-            s = (s + 1) & mask;
+            s = s + 1 == slots ? 0 : s + 1;
         }
     }
 }
@@ -137,11 +139,10 @@ s2k_status s2k_count_device(s2k_ctx *ctx, const uint64_t *d_hash, uint64_t n, ui
     if (!ctx || (!d_hash && n) || !n_distinct) return S2K_ERR_INVALID_ARG;
     hipStream_t st = ctx_stream(ctx);
     if (hipSetDevice(ctx_device(ctx)) != hipSuccess) return S2K_ERR_DEVICE;
-    uint64_t slots = 1024;
-    while (slots < 2 * n) slots <<= 1;
-    void *ws = nullptr;
+    const uint64_t slots = (n + n / 2 + 1024 + 255) & ~(uint64_t)255; // load factor <= 2/3
     const size_t bytes = slots * 12 + 64;
-    if (hipMalloc(&ws, bytes) != hipSuccess) {
+    void *ws = ctx_count_table(ctx, bytes);
+    if (!ws) {
         ctx_set_error(ctx, "s2k_count_device: table allocation");
         return S2K_ERR_NOMEM;
     }
@@ -153,7 +154,7 @@ s2k_status s2k_count_device(s2k_ctx *ctx, const uint64_t *d_hash, uint64_t n, ui
     if (e == hipSuccess) e = hipMemsetAsync(tcnt, 0, slots * 4 + 64, st);
     if (e == hipSuccess && n) {
         const uint64_t blocks = (n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536;
-        hipLaunchKernelGGL(count_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_hash, n, tkeys, tcnt, slots - 1, n_empty);
+        hipLaunchKernelGGL(count_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_hash, n, tkeys, tcnt, slots, n_empty);
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
@@ -165,7 +166,6 @@ s2k_status s2k_count_device(s2k_ctx *ctx, const uint64_t *d_hash, uint64_t n, ui
     unsigned long long total = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&total, cursor, 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(ws);
     if (e != hipSuccess) {
         ctx_set_error(ctx, "s2k_count_device: HIP error");
         return S2K_ERR_DEVICE;
@@ -179,8 +179,11 @@ s2k_status s2k_partition_device(s2k_ctx *ctx, const uint64_t *d_hash, uint64_t n
     if (!ctx || (!d_hash && n) || (!d_out && n) || !d_part_off || n_parts == 0 || n_parts > S2K_MAX_PARTS) return S2K_ERR_INVALID_ARG;
     hipStream_t st = ctx_stream(ctx);
     if (hipSetDevice(ctx_device(ctx)) != hipSuccess) return S2K_ERR_DEVICE;
-    unsigned long long *ws = nullptr;
-    if (hipMalloc((void **)&ws, 2 * S2K_MAX_PARTS * 8) != hipSuccess) return S2K_ERR_NOMEM;
+    unsigned long long *ws = (unsigned long long *)ctx_count_table(ctx, 2 * S2K_MAX_PARTS * 8);
+    if (!ws) {
+        ctx_set_error(ctx, "s2k_partition_device: workspace allocation");
+        return S2K_ERR_NOMEM;
+    }
     hipError_t e = hipMemsetAsync(ws, 0, 2 * S2K_MAX_PARTS * 8, st);
     const uint64_t blocks = n ? ((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384) : 1;
     if (e == hipSuccess) {
@@ -190,7 +193,6 @@ s2k_status s2k_partition_device(s2k_ctx *ctx, const uint64_t *d_hash, uint64_t n
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(ws);
     if (e != hipSuccess) {
         ctx_set_error(ctx, "s2k_partition_device: HIP error");
         return S2K_ERR_DEVICE;

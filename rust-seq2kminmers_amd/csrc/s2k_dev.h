@@ -61,12 +61,15 @@ struct Counts { // mirrored by s2k_counts (include/s2k.h)
     uint32_t hash_bound, path;
     // internal
     uint64_t pool_needed;
-    uint32_t pool_overflow, non_ascii, km_overflow, mn_overflow;
+    uint32_t pool_overflow, bad_input, km_overflow, mn_overflow; // bad_input: BAD_* bits set by validate_read_off_kernel
     uint64_t dbg_cycles[64][16]; // S2K_DEBUG_SKIP & 8: shader-clock cycles per phase, summed over waves
 #ifdef S2K_DEBUG_KNOBS
     uint64_t dbg_wave[4096][2];  // S2K_DEBUG_SKIP & 32: per wave {finish time (100 MHz) , XCC_ID << 32 | HW_ID}
 #endif
 };
+
+// what validate_read_off_kernel found wrong with a caller's device-resident read table (s2k_extract_device trusts nothing)
+enum : uint32_t { BAD_FIRST = 1u, BAD_ORDER = 2u, BAD_END = 4u, BAD_LONG = 8u };
 
 constexpr int XOR_SHARDS = 4096;
 
@@ -129,11 +132,15 @@ hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, u
                                const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint8_t *o_hpc,
                                uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle = false);
 
+// read_off[0] == 0, non-decreasing, read_off[n_reads] == n_bases, no read longer than 2^32 - 2: anything else sets BAD_*
+// bits in *bad (a device word); the kernels that follow in the stream look at it and do nothing when it is set
+hipError_t launch_validate_read_off(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint32_t *bad, hipStream_t st);
+
 hipError_t launch_synth(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d, hipStream_t st);
 
-hipError_t launch_serial_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, Sem sem,
+hipError_t launch_serial_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, Sem sem,
                                uint32_t *mn_cnt, hipStream_t st);
-hipError_t launch_serial_write(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, Sem sem,
+hipError_t launch_serial_write(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, Sem sem,
                                const uint64_t *mn_off, Records rec, Counts *counts, hipStream_t st);
 
 hipError_t launch_kminmers(uint64_t n_tiles, const uint64_t *tile_rec_off, const uint32_t *tile_cnt,

@@ -89,4 +89,6 @@ HostStager &ctx_stager(s2k_ctx *c);
 hipStream_t ctx_stream(s2k_ctx *c);
 int ctx_device(s2k_ctx *c);
 void ctx_set_error(s2k_ctx *c, const char *what);
+// grow-only device buffer of the context for s2k_count_device / s2k_partition_device (nullptr: allocation failed)
+void *ctx_count_table(s2k_ctx *c, size_t bytes);
 } // namespace s2k

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * KM_WAVES) void kminmer_kernel(
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t t = (uint64_t)blockIdx.x * KM_WAVES + w;
     if (t >= n_tiles) return; // whole wave exits together; no block-level barrier below
-    if (counts->pool_overflow) return; // record pool was too small: offsets are not valid, the host re-runs
+    if (counts->pool_overflow || counts->bad_input) return; // record pool too small (the host re-runs) / malformed read table
     const uint32_t cnt = tile_cnt[t];
     if (cnt == 0) return;
     const uint64_t roff = tile_rec_off[t];
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * KF_WAVES, 8) void kminmer_kernel_fast(
         mo = tile_rec_off[t + lane];
     }
     const uint64_t g0 = tile_goff[t];
-    const uint32_t pool_bad = counts->pool_overflow;
+    const uint32_t pool_bad = counts->pool_overflow | counts->bad_input;
     const uint32_t cnt = __shfl(mc, 0);
     if (cnt == 0 || pool_bad) return;
     const uint64_t roff = ((uint64_t)__shfl((uint32_t)(mo >> 32), 0) << 32) | __shfl((uint32_t)mo, 0);

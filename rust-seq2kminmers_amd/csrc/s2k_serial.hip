@@ -80,13 +80,23 @@ __device__ inline void walk_read(const uint8_t *__restrict__ s, uint64_t n, cons
     }
 }
 
+// A caller's device-resident read table is validated by a kernel earlier in the stream (validate_read_off_kernel) whose
+// verdict the host sees only afterwards: until then a malformed entry must not turn into an out-of-bounds read.
+__device__ inline void clamp_read(uint64_t &a, uint64_t &b, uint64_t n_bases) {
+    if (a > n_bases) a = n_bases;
+    if (b > n_bases) b = n_bases;
+    if (b < a) b = a;
+    if (b - a > 0xFFFFFFFEull) b = a + 0xFFFFFFFEull;
+}
+
 template <bool HPC, class Seeds>
 __global__ __launch_bounds__(64) void serial_count_kernel(const uint8_t *__restrict__ bases,
-                                                          const uint64_t *__restrict__ read_off, uint64_t n_reads,
+                                                          const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
                                                           Sem sem, uint32_t *__restrict__ mn_cnt) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     uint64_t a = read_off[r], b = read_off[r + 1];
+    clamp_read(a, b, n_bases);
     uint32_t c = 0;
     walk_read<HPC, Seeds>(bases + a, b - a, sem, [&](uint32_t, uint32_t, uint32_t) { c++; });
     mn_cnt[r] = c;
@@ -94,12 +104,13 @@ __global__ __launch_bounds__(64) void serial_count_kernel(const uint8_t *__restr
 
 template <bool HPC, class Seeds>
 __global__ __launch_bounds__(64) void serial_write_kernel(const uint8_t *__restrict__ bases,
-                                                          const uint64_t *__restrict__ read_off, uint64_t n_reads,
+                                                          const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
                                                           Sem sem, const uint64_t *__restrict__ mn_off, Records rec,
                                                           Counts *counts) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     uint64_t a = read_off[r], b = read_off[r + 1];
+    clamp_read(a, b, n_bases);
     uint64_t o = mn_off[r];
     if (r == 0 && mn_off[n_reads] > rec.capacity) {
         counts->pool_overflow = 1;
@@ -148,30 +159,30 @@ __global__ __launch_bounds__(64) void hpc_write_kernel(const uint8_t *__restrict
 
 } // namespace
 
-hipError_t launch_serial_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, Sem sem,
+hipError_t launch_serial_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, Sem sem,
                                uint32_t *mn_cnt, hipStream_t st) {
     if (n_reads == 0) return hipSuccess;
     dim3 g((unsigned)((n_reads + 63) / 64)), b(64);
     if (sem.hpc) {
-        if (sem.simd_seeds) hipLaunchKernelGGL((serial_count_kernel<true, SeedsSimd>), g, b, 0, st, bases, read_off, n_reads, sem, mn_cnt);
-        else hipLaunchKernelGGL((serial_count_kernel<true, SeedsScalar>), g, b, 0, st, bases, read_off, n_reads, sem, mn_cnt);
+        if (sem.simd_seeds) hipLaunchKernelGGL((serial_count_kernel<true, SeedsSimd>), g, b, 0, st, bases, read_off, n_reads, n_bases, sem, mn_cnt);
+        else hipLaunchKernelGGL((serial_count_kernel<true, SeedsScalar>), g, b, 0, st, bases, read_off, n_reads, n_bases, sem, mn_cnt);
     } else {
-        if (sem.simd_seeds) hipLaunchKernelGGL((serial_count_kernel<false, SeedsSimd>), g, b, 0, st, bases, read_off, n_reads, sem, mn_cnt);
-        else hipLaunchKernelGGL((serial_count_kernel<false, SeedsScalar>), g, b, 0, st, bases, read_off, n_reads, sem, mn_cnt);
+        if (sem.simd_seeds) hipLaunchKernelGGL((serial_count_kernel<false, SeedsSimd>), g, b, 0, st, bases, read_off, n_reads, n_bases, sem, mn_cnt);
+        else hipLaunchKernelGGL((serial_count_kernel<false, SeedsScalar>), g, b, 0, st, bases, read_off, n_reads, n_bases, sem, mn_cnt);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_serial_write(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, Sem sem,
+hipError_t launch_serial_write(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, Sem sem,
                                const uint64_t *mn_off, Records rec, Counts *counts, hipStream_t st) {
     if (n_reads == 0) return hipSuccess;
     dim3 g((unsigned)((n_reads + 63) / 64)), b(64);
     if (sem.hpc) {
-        if (sem.simd_seeds) hipLaunchKernelGGL((serial_write_kernel<true, SeedsSimd>), g, b, 0, st, bases, read_off, n_reads, sem, mn_off, rec, counts);
-        else hipLaunchKernelGGL((serial_write_kernel<true, SeedsScalar>), g, b, 0, st, bases, read_off, n_reads, sem, mn_off, rec, counts);
+        if (sem.simd_seeds) hipLaunchKernelGGL((serial_write_kernel<true, SeedsSimd>), g, b, 0, st, bases, read_off, n_reads, n_bases, sem, mn_off, rec, counts);
+        else hipLaunchKernelGGL((serial_write_kernel<true, SeedsScalar>), g, b, 0, st, bases, read_off, n_reads, n_bases, sem, mn_off, rec, counts);
     } else {
-        if (sem.simd_seeds) hipLaunchKernelGGL((serial_write_kernel<false, SeedsSimd>), g, b, 0, st, bases, read_off, n_reads, sem, mn_off, rec, counts);
-        else hipLaunchKernelGGL((serial_write_kernel<false, SeedsScalar>), g, b, 0, st, bases, read_off, n_reads, sem, mn_off, rec, counts);
+        if (sem.simd_seeds) hipLaunchKernelGGL((serial_write_kernel<false, SeedsSimd>), g, b, 0, st, bases, read_off, n_reads, n_bases, sem, mn_off, rec, counts);
+        else hipLaunchKernelGGL((serial_write_kernel<false, SeedsScalar>), g, b, 0, st, bases, read_off, n_reads, n_bases, sem, mn_off, rec, counts);
     }
     return hipGetLastError();
 }

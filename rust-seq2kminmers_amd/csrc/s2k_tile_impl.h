@@ -9,31 +9,36 @@
 //  * The batch of reads is one byte stream; the stream is cut into fixed tiles of 64 x 144 = 9216
 //    bases, one wave per tile, independent of read lengths.  l-mers that straddle a read boundary
 //    are cleared from the hit masks afterwards, so ragged reads cost nothing in the hot loop.
-//  * Persistent waves: a wave walks tiles t, t + n_waves, ...; the next tile's bytes (and the read-table
-//    entries of the next two tiles) are in flight into registers while the current tile is processed, so
-//    no global-load latency sits on the critical path after the first tile.
-//  * A tile is staged in LDS (1 KiB per wave-instruction).  Each lane then owns 144 consecutive l-mer
-//    start positions and *rolls* the hash privately (fh' = rotl(fh,1) ^ OUT[s[p]] ^ IN[s[p+l]]), reading
-//    its bytes from LDS in 16 B pieces (lane stride 16*odd bytes: bank-conflict free) and its seeds from
-//    two 256-entry LDS tables that have the rotations pre-applied (one ds_read_b64 each, one SDWA
-//    instruction per base for the address).  A lane pays an l-base warm-up instead of a cross-lane scan.
-//  * Minimizers are rare (~2 % of positions), but a per-position branch would be taken by almost every
-//    wave (64 lanes x 2 %).  So the hot loop is branch-free: per position it records a hit bit and keeps
-//    the hash of the last hit of each 8-position piece (compare -> select -> add-with-carry through VCC).
-//  * Dense phase: read starts become hash-space boundaries and invalid l-mers are cleared from the masks
-//    by range; popcounts + one DPP scan give every lane its output offset; lanes list their hits; then one
-//    lane per hit finds its read among the read starts kept in LDS, back-maps positions and writes the
-//    record with coalesced stores.  The ~7 % of hits that were not the last of their piece are queued and
-//    re-derived from their l bytes, one lane per hit.  No global LOAD sits in that loop: one would make
-//    the compiler drain every outstanding store of the previous round.
-//  * Hpc mode first compacts the tile's run heads in place in LDS (SWAR byte compares, per-lane
-//    popcounts, one wave scan, overwrite-style byte stores), appends the l run heads that follow the
-//    tile (first from the staged look-ahead, then by a loop over the stream, so arbitrarily long
-//    homopolymers are fine), and then runs the same hash loop over the compacted bytes.  Raw positions
-//    are recovered for hits only, from the per-lane flag masks (owner-lane hint table + select-nth-bit).
-//    Read starts are forced run heads: they are marked with bit 7 of the staged byte, which is why
-//    Hpc tiles require 7-bit input (a byte >= 0x80 raises `non_ascii` and the host re-runs the call on
-//    the exact serial kernels).
+//  * Persistent waves, tiles dealt DYNAMICALLY: a wave takes its first three tiles statically (the software pipeline
+//    is three deep) and every later one from one of 64 cursors in global memory (one atomic per tile, issued at the
+//    top of an iteration and looked at after the hash loop).  Everything per tile lives in SGPRs.
+//  * A tile's 9344 bytes (9216 + 128 B look-ahead) go from global memory STRAIGHT into the wave's LDS buffer
+//    (global_load_lds_dwordx4, issued from inline asm, 1 KiB per wave-instruction, no registers, no ds_write) while
+//    the previous tile's one-lane-per-hit rounds run; the top of an iteration waits for them with a COUNTED
+//    s_waitcnt vmcnt(n) that leaves the record stores issued after them in flight (see stores_after_dma below and
+//    tests/test_isa_invariants.py, which checks the count against the disassembly).
+//  * Each lane owns 144 consecutive l-mer start positions and *rolls* the hash privately
+//    (fh' = rotl(fh,1) ^ OUT[s[p]] ^ IN[s[p+l]]), reading its bytes from LDS in 16 B pieces (lane stride 16*odd bytes:
+//    bank-conflict free) and its seeds from two 256-entry LDS tables that have the rotations pre-applied (one
+//    ds_read_b64 each, one SDWA instruction per base for the address).  A lane pays an l-base warm-up instead of a
+//    cross-lane scan.
+//  * Minimizers are rare (~2 % of positions), but a per-position branch would be taken by almost every wave
+//    (64 lanes x 2 %).  So the hot loop is branch-free: per position it shifts a hit bit into a register and keeps the
+//    hash of the last hit of each 16-position piece (compare -> select -> add-with-carry through VCC).  Hit bits
+//    (5 registers) and kept hashes (9 registers) stay in VGPRs.
+//  * Dense phase: read starts become hash-space boundaries and invalid l-mers are cleared from the masks by range;
+//    popcounts + one DPP scan give every lane its output offset; lanes list their hits (16-bit entries in LDS); the
+//    ~14 % of hits that were not the last of their piece are queued and re-derived from their l bytes, four lanes per
+//    hit, BEFORE the rounds (from then on the tile's bytes are dead and the next tile is loaded into the same buffer);
+//    then one lane per hit finds its read among the read starts kept in LDS, back-maps positions and writes the record
+//    with coalesced stores.  No global LOAD sits in that loop: one would make the compiler drain every outstanding
+//    store of the previous round.
+//  * Hpc mode first compacts the tile's run heads in place in LDS (SWAR byte compares -> v_dot4 nibbles -> per-lane
+//    flag masks in natural bit order, popcounts, one wave scan, overwrite-style byte stores), appends the l run heads
+//    that follow the tile (first from the staged look-ahead, then by a loop over the stream, so arbitrarily long
+//    homopolymers are fine), and then runs the same hash loop over the compacted bytes.  Raw positions are recovered
+//    for hits only, from the per-lane flag masks (owner-lane hint table + select-nth-bit).  Read starts are forced run
+//    heads: they are OR-ed into the flag masks; the staged bytes are never modified, so ANY byte value is fine.
 //  * Records go to a fixed per-tile slab (mean + 6 sigma); only a tile with more hits takes space from a
 //    shared overflow region with one atomic.  (One shared cursor for every tile serialised the kernel.)
 //
@@ -63,6 +68,7 @@ constexpr int JOBCAP = 32;                             // queued hash re-derivat
 constexpr int REG_LA = 1;
 constexpr int HPC_LA = 2;                              // seed look-ahead (positions) of the Hpc hash loop: 8 spills there
 constexpr int NBL = 32;                                // read starts of a tile kept in LDS (hb / rs); tiles with more search the read table
+constexpr int STORES_PER_ROUND = 3;                    // vector-memory operations one round of 64 hits issues (j, jend, rid): the counted vmcnt wait relies on it
 constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
 
 struct HpcLds {
@@ -124,27 +130,6 @@ __device__ inline uint32_t select_nth_32(uint32_t w, uint32_t n) {
     c = w & 1u;              if (n >= c) { r += 1; }
     return r;
 }
-// bit i of a byte -> bit 4i
-__device__ inline uint32_t spread4(uint32_t x) {
-    x = (x | (x << 12)) & 0x000F000Fu;
-    x = (x | (x << 6)) & 0x03030303u;
-    x = (x | (x << 3)) & 0x11111111u;
-    return x;
-}
-// flag-mask group (bit 8b+d <-> byte 4d+b) -> natural order (bit 4d+b)
-__device__ inline uint32_t untranspose(uint32_t u) {
-    return spread4(u & 0xFFu) | (spread4((u >> 8) & 0xFFu) << 1) | (spread4((u >> 16) & 0xFFu) << 2) |
-           (spread4(u >> 24) << 3);
-}
-// bits of a group mask that belong to bytes at or before (d, b) in byte order
-__host__ __device__ constexpr uint32_t at_or_before(int d, int b) {
-    uint32_t m = 0;
-    for (int bb = 0; bb < 4; bb++)
-        for (int dd = 0; dd < 8; dd++)
-            if (dd < d || (dd == d && bb <= b)) m |= 1u << (8 * bb + dd);
-    return m;
-}
-
 // Seed look-ups of the hot loop.  The two 2 KiB tables sit at LDS byte offsets 0 (IN pairs) and 2048 (OUT
 // pairs); the kernel has no static LDS, so the dynamic region starts at 0 (checked at kernel entry).  The byte
 // offset of a base's entries is formed ONCE, when the base enters the window, by one v_lshlrev_b32_sdwa (byte
@@ -914,6 +899,9 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
         constexpr bool MANY = decltype(many_c)::value;
         constexpr int U = 1; // hits per lane per iteration (two overlapped back-maps cost ~25 VGPRs: three waves per SIMD matter more)
         for (uint32_t k0 = 0; k0 < bn; k0 += 64 * U) {
+            // (markers for tools/isa/check_vmcnt.py: the loop body must issue the STORES_PER_ROUND vector-memory operations the
+            // counted wait at the top of the next tile relies on)
+            asm volatile("; S2K_MARK round_begin many=%0" ::"i"(MANY ? 1 : 0));
             uint32_t kk[U], x[U], rid[U];
             bool act[U];
 #pragma unroll
@@ -988,6 +976,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                     }
                 }
             }
+            asm volatile("; S2K_MARK round_end many=%0" ::"i"(MANY ? 1 : 0));
         }
         };
         // > NBL - 2 reads starting in one tile take the variant that searches the read table itself; keeping it a
@@ -998,10 +987,10 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     return N;
 }
 
-// Persistent kernel: every wave walks tiles t = wave_id, wave_id + n_waves, ...  While a tile is being
-// hashed, the next tile's 9344 bytes are already in flight into registers (NPRE x 16 B per lane), and the
-// read-table entries of the current tile are fetched before they are needed, so no global-load latency
-// sits on the critical path except in the first iteration.
+// Persistent kernel: a wave takes tiles wave_id, wave_id + n_waves, wave_id + 2 n_waves and then draws from the cursors.
+// While the rounds of a tile run, the next tile's 9344 bytes are in flight into the wave's LDS buffer (LDS-DMA), and the
+// read-table entries of the next tiles are fetched before they are needed, so no global-load latency sits on the critical
+// path except in the first iteration.
 template <int L, bool HPC>
 __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
@@ -1026,6 +1015,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     const uint64_t n_waves = (uint64_t)gridDim.x * TW;
     uint64_t t = (uint64_t)blockIdx.x * TW + w;
     if (t >= n_tiles) return;
+    if (__builtin_amdgcn_readfirstlane((int)counts->bad_input)) return; // malformed read table (validate_read_off_kernel): touch nothing
     uint64_t stamp = __builtin_amdgcn_s_memtime();
     uint64_t ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -1130,6 +1120,8 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         if (__builtin_amdgcn_readfirstlane((int)have_pre)) { // a scalar branch: as a divergent if/else the slow path's loads would precede this wait
             // loaded into the buffer by the previous iteration (prologue: just now): wait for the loads, nothing to move.
             // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; 0x0F70 = vmcnt(0) only
+            static_assert(STORES_PER_ROUND == 3, "the cases below are 1 .. 4 rounds of STORES_PER_ROUND operations");
+            asm volatile("; S2K_MARK counted_wait per_round=%0" ::"i"(STORES_PER_ROUND));
             switch (__builtin_amdgcn_readfirstlane((int)stores_after_dma)) { // wave-uniform, and the compiler should know
                 case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
                 case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
@@ -1262,7 +1254,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         {
             const bool many = (cr1 - cr0) > (uint32_t)(NBL - 2) || (sem.dbg_skip & 16) != 0; // (KNOBS builds: stores ablated)
             const uint32_t last = N == 0 ? 0u : N - ((N - 1) / (uint32_t)LISTCAP) * (uint32_t)LISTCAP;
-            stores_after_dma = many ? 0u : 3u * ((last + 63u) / 64u);
+            stores_after_dma = many ? 0u : (uint32_t)STORES_PER_ROUND * ((last + 63u) / 64u);
         }
         wave_sync(); // LDS of this wave is reused by the next tile
         r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; prevb = prevbn; // rotate the pipeline
@@ -1298,6 +1290,7 @@ __global__ __launch_bounds__(256) void tile_index_kernel(const uint64_t *__restr
                                                          uint32_t *__restrict__ tile_read0) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
+    // (a malformed table only makes this search return some index in [0, n_reads); the kernels that follow do nothing then)
     uint64_t pos = t * (uint64_t)TILE_BASES;
     if (pos > n_bases) pos = n_bases;
     uint64_t lo = 0, hi = n_reads - 1;

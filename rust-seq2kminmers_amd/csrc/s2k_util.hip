@@ -267,9 +267,12 @@ __global__ __launch_bounds__(256) void read_run_counts(const uint8_t *__restrict
     const int sub = (int)(gid & 15);
     const bool live = r < n_reads; // whole groups of 16 are live or not: the shuffles below stay inside a group
     uint64_t a = 0, b = 0;
-    if (live) {
+    if (live) { // entries of a malformed table (see validate_read_off_kernel) must not become out-of-bounds reads
         a = read_off[r];
         b = read_off[r + 1];
+        if (a > n) a = n;
+        if (b > n) b = n;
+        if (b < a) b = a;
     }
     uint32_t pa = 0, pb = 0;
     if (live && b > a) {
@@ -294,6 +297,32 @@ __global__ __launch_bounds__(256) void read_run_counts(const uint8_t *__restrict
     runs[r] = R;
 }
 } // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void validate_read_off_kernel(const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
+                                                                uint32_t *__restrict__ bad) {
+    uint32_t f = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += stride) {
+        const uint64_t a = read_off[r], b = read_off[r + 1];
+        if (b < a) f |= BAD_ORDER;
+        else if (b - a > 0xFFFFFFFEull) f |= BAD_LONG;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (read_off[0] != 0) f |= BAD_FIRST;
+        if (read_off[n_reads] != n_bases) f |= BAD_END;
+    }
+    if (f) atomicOr(bad, f);
+}
+} // namespace
+
+hipError_t launch_validate_read_off(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint32_t *bad, hipStream_t st) {
+    uint64_t blocks = (n_reads + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(validate_read_off_kernel, dim3((unsigned)blocks), dim3(256), 0, st, read_off, n_reads, n_bases, bad);
+    return hipGetLastError();
+}
 
 hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                   uint32_t *blk_cnt, uint64_t *blk_off, uint64_t *scan_tmp, uint32_t *runs, uint64_t *read_c0,

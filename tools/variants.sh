@@ -5,6 +5,7 @@
 cd $GRAFT_REPO_ROOT
 H=rust-seq2kminmers_amd/csrc/s2k_tile_impl.h
 cp $H /tmp/impl.orig
+trap 'cp /tmp/impl.orig $H' EXIT  # also when the script is killed half way
 run() {
   rm -f rust-seq2kminmers_amd/csrc/s2k_tile*.o  # (object mtimes come from the build host: force the rebuild)
   make -s -C rust-seq2kminmers_amd/csrc -j16 libs2k.so > /tmp/make.log 2>&1 || { echo "BUILD FAILED: $1"; tail -3 /tmp/make.log; return; }
