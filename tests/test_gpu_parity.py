@@ -296,6 +296,62 @@ def test_status_codes(eng):
     assert eng.extract(b, off, 31, 5, 0.1, 0)["n"] >= 0  # the context stays usable after errors
 
 
+def test_device_read_table_is_validated_on_the_device(eng, oracle):
+    """s2k_extract_device trusts nothing about a read table that lives in HBM: a table that does not start at 0, is not
+    non-decreasing or does not end at n_bases comes back as S2K_ERR_INVALID_ARG (not as an out-of-bounds device read),
+    synchronously and through s2k_sync; the standalone HPC op checks the same; the context stays usable."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    reads = [rand_read(rng, 20000, hp=0.2) for _ in range(40)]
+    bases, off = pkg.pack_reads(reads)
+    dev = torch.device("cuda", 0)
+    d_b = torch.from_numpy(bases).to(dev)
+    n_reads, n_bases = len(reads), len(bases)
+    cap = 40000
+    t = {"km_off": torch.zeros(n_reads + 1, dtype=torch.int64, device=dev), "hash": torch.zeros(cap, dtype=torch.int64, device=dev),
+         "start": torch.zeros(cap, dtype=torch.int32, device=dev), "end": torch.zeros(cap, dtype=torch.int32, device=dev),
+         "rev": torch.zeros(cap, dtype=torch.uint8, device=dev)}
+    o = pkg.DeviceOut()
+    o.km_capacity = cap
+    o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+    good = off.astype(np.int64)
+    bad_tables = []
+    b = good.copy(); b[0] = 5; bad_tables.append(b)                      # does not start at 0
+    b = good.copy(); b[7], b[8] = good[8], good[7]; bad_tables.append(b)  # not monotone
+    b = good.copy(); b[-1] += 100; bad_tables.append(b)                   # ends past n_bases
+    b = good.copy(); b[20:] = 1 << 45; bad_tables.append(b)               # garbage far outside the stream
+    b = np.zeros_like(good); bad_tables.append(b)                         # all zero: ends before n_bases
+    for mode in (HM.Regular, HM.Hpc, HM.HpcSimd):
+        for flags in (0, pkg.FLAG_FORCE_SERIAL):
+            for b in bad_tables:
+                d_o = torch.from_numpy(b).to(dev)
+                torch.cuda.synchronize()
+                with pytest.raises(pkg.S2kError) as e:
+                    eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, 31, 10, 0.01, int(mode), o, flags=flags)
+                assert e.value.status == 1, (int(mode), flags)
+                eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, 31, 10, 0.01, int(mode), o, sync=False, flags=flags)
+                with pytest.raises(pkg.S2kError) as e:
+                    eng.sync()
+                assert e.value.status == 1
+    # standalone HPC op
+    d_o = torch.from_numpy(bad_tables[1]).to(dev)
+    d_ho = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.S2kError) as e:
+        eng.hpc_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, d_ho.data_ptr(), 0, 0, 0)
+    assert e.value.status == 1
+    # the good table still works on the same context, bit for bit
+    d_o = torch.from_numpy(good).to(dev)
+    torch.cuda.synchronize()
+    c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, 31, 10, 0.01, int(HM.Hpc), o)
+    ref = oracle.batch(bases, off, 31, 10, 0.01, OMODE[HM.Hpc])
+    assert c["n_kminmers"] == ref["n"] and (t["hash"][: ref["n"]].cpu().numpy().view(np.uint64) == ref["hash"]).all()
+    eng.trim()  # s2k_trim: buffers grow again on demand
+    c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, 31, 10, 0.01, int(HM.Regular), o)
+    assert c["n_kminmers"] == oracle.batch(bases, off, 31, 10, 0.01, OMODE[HM.Regular])["n"]
+
+
 def test_device_api_capacity_and_async(eng, oracle):
     import torch
 
