@@ -81,7 +81,8 @@ typedef struct s2k_counts {
     uint64_t n_kminmers;
     uint64_t xor_hash;   /* XOR of all k-min-mer hashes (cheap whole-run checksum) */
     uint32_t hash_bound; /* the u32 bound of src/lib.rs:91 that was used */
-    uint32_t path;       /* 0 = tiled kernels, 1 = read-serial kernels */
+    uint32_t path;       /* 0 = tiled kernel, single pass (it writes the k-min-mers itself); 1 = read-serial kernels;
+                          * 2 = tiled kernel + k-min-mer kernel (k > 32, or a tile with more than 30 read starts) */
 } s2k_counts;
 
 /* Host-side result, SoA.  Item i of read r (km_off[r] <= i < km_off[r+1]) is

@@ -155,6 +155,8 @@ struct Call { // everything needed to (re-)enqueue one extraction
     Sem sem{};
     uint32_t bound = 0;
     bool serial = false;
+    bool fused_run = false; // what the last enqueue() took
+    bool no_fused = false; // the fused single-pass path met something it does not handle: the re-run takes the two-kernel path
     uint64_t pool_cap = 0; // serial: dense record capacity; tiled: capacity of the overflow region
     uint64_t slab_cap = 0; // tiled: records per tile slab
     bool valid = false;
@@ -315,6 +317,13 @@ s2k_status enqueue(s2k_ctx *ctx) {
     uint32_t *mn_cnt = nullptr, *tile_read0 = nullptr, *tile_cnt = nullptr;
     uint64_t *mn_off = nullptr, *tile_rec_off = nullptr, *tile_goff = nullptr, *scan_tmp = nullptr, *pool_cursor = nullptr;
     const bool want_runs = !c.serial && c.sem.hpc && c.sem.tail_quirk; // HpcSimd on the tiled kernel
+    // fused single-pass path: the tiled kernel writes the final k-min-mers itself (no record pool, no scans, no second kernel)
+    const bool fused = !c.serial && !c.no_fused && n_tiles >= 1 && n_reads >= 1 && c.sem.k <= 32;
+    c.fused_run = fused;
+    TileDesc *desc = nullptr;
+    uint8_t *edge = nullptr;
+    uint64_t *totals = nullptr;
+    Fused *d_fz = nullptr;
     const uint64_t n_runblk = n_bases / 256 + 1;
     uint32_t *run_blk = nullptr, *read_runs = nullptr;
     uint64_t *run_off = nullptr, *run_tmp = nullptr;
@@ -337,7 +346,13 @@ s2k_status enqueue(s2k_ctx *ctx) {
             run_tmp = a.take<uint64_t>(scan_tmp_bytes(n_runblk) / sizeof(uint64_t) + 1);
             read_runs = a.take<uint32_t>(n_reads + 1);
         }
-        const uint64_t rec_total = c.serial ? c.pool_cap : n_tiles * c.slab_cap + c.pool_cap;
+        if (fused) {
+            desc = a.take<TileDesc>(n_tiles);
+            edge = a.take<uint8_t>(n_tiles * (uint64_t)edge_stride(c.sem.k));
+            totals = a.take<uint64_t>(2);
+            d_fz = a.take<Fused>(1);
+        }
+        const uint64_t rec_total = fused ? 0 : (c.serial ? c.pool_cap : n_tiles * c.slab_cap + c.pool_cap);
         rec.j = a.take<uint32_t>(rec_total);
         rec.jend = a.take<uint32_t>(rec_total);
         rec.hash = a.take<uint32_t>(rec_total);
@@ -393,9 +408,42 @@ s2k_status enqueue(s2k_ctx *ctx) {
                     "run count kernels");
             sem.read_runs = read_runs;
         }
+        if (fused) {
+            Fused fz{};
+            fz.desc = desc;
+            fz.edge = edge;
+            fz.k = c.sem.k;
+            fz.km_capacity = o.km_capacity;
+            fz.mn_capacity = o.mn_capacity;
+            fz.o_km_off = (unsigned long long *)o.km_off;
+            fz.o_hash = (unsigned long long *)o.hash;
+            fz.o_start = o.start;
+            fz.o_end = o.end;
+            fz.o_rev = o.rev;
+            fz.o_mn_off = (unsigned long long *)mn_off; // the caller's, or workspace
+            fz.o_mn_j = o.mn_j;
+            fz.o_mn_jend = o.mn_jend;
+            fz.o_mn_hash = o.mn_hash;
+            fz.xor_shards = (unsigned long long *)ctx->d_xor;
+            fz.totals = (unsigned long long *)totals;
+            S2K_TRY(hipMemsetAsync(desc, 0, n_tiles * sizeof(TileDesc), st), "memset tile descriptors");
+            if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
+            S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, nullptr,
+                                           nullptr, nullptr, ctx->d_counts, &fz, d_fz, st),
+                    "tiled minimizer kernel (fused)");
+            if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
+            if (tm) S2K_TRY(hipEventRecord(ctx->ev[3], st), "event");
+            S2K_TRY(launch_fused_fixup(n_tiles, fz, ctx->d_counts, st), "fix-up kernel");
+            if (tm) S2K_TRY(hipEventRecord(ctx->ev[4], st), "event");
+            S2K_TRY(launch_finalize(ctx->d_counts, ctx->d_xor, totals, totals + 1, o.km_capacity, o.mn_capacity, st), "finalize kernel");
+            S2K_TRY(hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(Counts), hipMemcpyDeviceToHost, st), "counts copy");
+            if (tm) S2K_TRY(hipEventRecord(ctx->ev[5], st), "event");
+            ctx->pending = true;
+            return S2K_OK;
+        }
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
         S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
-                                       tile_rec_off, tile_cnt, mn_cnt, ctx->d_counts, st),
+                                       tile_rec_off, tile_cnt, mn_cnt, ctx->d_counts, nullptr, nullptr, st),
                 "tiled minimizer kernel");
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
         S2K_TRY(launch_scan_u32(tile_cnt, n_tiles, tile_goff, scan_tmp, 0, st), "scan");
@@ -435,6 +483,13 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
             c.valid = false;
             return ctx->pending_status;
         }
+        if (h->need_unfused) { // the fused path met a tile with more read starts than it keeps in LDS (reads shorter than ~300
+                               // bases), or a look-back gave up: the whole call takes the two-kernel path
+            c.no_fused = true;
+            s2k_status st = enqueue(ctx);
+            if (st != S2K_OK) return st;
+            continue;
+        }
         if (h->pool_overflow) { // record pool (serial) / overflow region (tiled) too small: re-run with the exact size
             c.pool_cap = h->pool_needed + h->pool_needed / 64 + (uint64_t)TILE_BASES + 4096;
             s2k_status st = enqueue(ctx);
@@ -444,7 +499,7 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
         h->n_reads = c.n_reads;
         h->n_bases = c.n_bases;
         h->hash_bound = c.bound;
-        h->path = c.serial ? 1u : 0u;
+        h->path = c.serial ? 1u : (c.fused_run ? 0u : 2u);
         if (c.sem.dbg_skip & 32) // KNOBS builds: spread of the waves' finishing times in the tiled kernel
         {
             fprintf(stderr, "[s2k dbg] last wave finished %.1f us after the first\n", (double)(h->dbg_cycles[0][0] - ~h->dbg_cycles[0][1]) * 0.01);

@@ -62,6 +62,9 @@ struct Counts { // mirrored by s2k_counts (include/s2k.h)
     // internal
     uint64_t pool_needed;
     uint32_t pool_overflow, bad_input, km_overflow, mn_overflow; // bad_input: BAD_* bits set by validate_read_off_kernel
+    uint32_t need_unfused, pad2_;
+    uint32_t lb_polls[64]; // look-back polls of the fused path (diagnostics), sharded
+    // fused path: a tile it cannot handle was met (or a look-back timed out): the host re-runs the call unfused
     uint64_t dbg_cycles[64][16]; // S2K_DEBUG_SKIP & 8: shader-clock cycles per phase, summed over waves
 #ifdef S2K_DEBUG_KNOBS
     uint64_t dbg_wave[4096][2];  // S2K_DEBUG_SKIP & 32: per wave {finish time (100 MHz) , XCC_ID << 32 | HW_ID}
@@ -99,6 +102,54 @@ struct Records { // SoA pool of minimizer records written by the minimizer kerne
     // with one atomic.  A single shared cursor for every tile serialises the whole kernel (~88 atomics
     // per microsecond on one address = 12 ms for 1.1 M tiles).
     uint64_t slab_cap, ovf_base;
+};
+
+// ---- fused single-pass emission: the tile kernel writes the final k-min-mers itself (s2k_tile_impl.h, FUSED = true) -------------
+// Output offsets need a prefix sum over the tiles; it is carried from tile to tile inside the kernel (decoupled look-back over
+// one descriptor per tile, every word self-validating: a 64-bit agent-scope store / load each, no fences).  What travels along
+// the tiles is the pair (G, p): G = k-min-mers (and, beside it, minimizers) before the tile, p = min(k-1, minimizers the read
+// that continues into the tile has so far).  A tile's own contribution is a small function of p -- see agg_* below.
+struct TileDesc {
+    unsigned long long agg;  // the tile alone: valid | poison | pass | dep | q | N | C | m_f
+    unsigned long long pre0; // everything up to and including the tile: valid | poison | p | G (k-min-mers)
+    unsigned long long pre1; // ... valid | G (minimizers)
+    unsigned long long pad;
+};
+constexpr unsigned long long TD_VALID = 1ull << 63, TD_POISON = 1ull << 62;
+// agg word: m_f bits [0,14) = minimizers of the tile's first read segment, C [14,28) = k-min-mers ending in the tile that do not
+// depend on p, N [28,42) = minimizers of the tile, q [42,48), dep bit 48, pass bit 49:
+//   k-min-mers ending in the tile = C + (dep ? max(0, m_f - (k-1) + p) : 0);   p after the tile = pass ? min(k-1, p + m_f) : q
+__host__ __device__ inline unsigned long long agg_pack(uint32_t m_f, uint32_t C, uint32_t N, uint32_t q, bool dep, bool pass) {
+    return TD_VALID | (unsigned long long)m_f | ((unsigned long long)C << 14) | ((unsigned long long)N << 28) | ((unsigned long long)q << 42) |
+           ((unsigned long long)(dep ? 1 : 0) << 48) | ((unsigned long long)(pass ? 1 : 0) << 49);
+}
+// Per tile, for the fix-up kernel that emits the k-min-mers whose minimizers lie in more than one tile: a header and the
+// first / last k-1 minimizers of the tile's first / last read segment.
+struct EdgeHdr {
+    unsigned long long g_excl; // k-min-mers before the tile
+    uint32_t p_in;             // min(k-1, minimizers of the continuing read before the tile); 0 when the tile starts a read
+    uint32_t n_head;           // entries of head[]: min(k-1, minimizers of the first segment), 0 when no read continues into the tile
+    uint32_t n_tail;           // entries of tail[]: min(k-1, minimizers of the last segment)
+    uint32_t flags;            // bit 0: the tile is one segment of a read that began earlier (walk further back for more)
+    unsigned long long pad;
+};
+struct EdgeRec {
+    uint32_t hash, pos; // head[]: pos = jend; tail[]: pos = j
+};
+__host__ __device__ inline uint32_t edge_stride(uint32_t k) { return (uint32_t)sizeof(EdgeHdr) + 2u * (k - 1u) * (uint32_t)sizeof(EdgeRec); }
+
+struct Fused { // arguments of the fused path (all device pointers)
+    TileDesc *desc;      // n_tiles, zeroed before the launch
+    uint8_t *edge;       // n_tiles x edge_stride(k)
+    uint32_t k, pad_;
+    unsigned long long km_capacity, mn_capacity;
+    unsigned long long *o_km_off, *o_hash;
+    uint32_t *o_start, *o_end;
+    uint8_t *o_rev;
+    unsigned long long *o_mn_off; // with mn_capacity != 0
+    uint32_t *o_mn_j, *o_mn_jend, *o_mn_hash;
+    unsigned long long *xor_shards;
+    unsigned long long *totals;   // [0] minimizers, [1] k-min-mers of the whole call (written by the last tile)
 };
 
 #define S2K_HIP_CHECK(expr)                                                      \
@@ -153,10 +204,13 @@ hipError_t launch_finalize(Counts *counts, const uint64_t *xor_shards, const uin
 
 hipError_t launch_tile_index(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles,
                              uint32_t *tile_read0, hipStream_t st);
+// fused != nullptr: single pass, final k-min-mers written by the kernel (rec / tile_rec_off / tile_cnt / mn_cnt unused)
 hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                   uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec,
                                   uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
-                                  Counts *counts, hipStream_t st);
+                                  Counts *counts, const Fused *fused, Fused *d_fused /* device scratch for *fused */, hipStream_t st);
+// the k-min-mers whose k minimizers lie in more than one tile (fused path), from the tiles' edge records
+hipError_t launch_fused_fixup(uint64_t n_tiles, Fused fz, const Counts *counts, hipStream_t st);
 
 hipError_t launch_hpc_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint32_t *run_cnt, hipStream_t st,
                             bool rle = false);

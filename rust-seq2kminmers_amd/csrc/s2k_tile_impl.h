@@ -57,7 +57,8 @@
 namespace s2k {
 namespace {
 
-constexpr int TW = 4;                                  // waves per block (they share the two seed tables)
+constexpr int TW = 12;                                 // waves per block = all the waves of a CU (three per SIMD): ONE block per CU shares the two seed
+                                                       // tables, which leaves every wave ~1 KB more LDS than three blocks of four did (fused emission needs it)
 constexpr int HS_OFF = 16;                             // data starts here; byte HS_OFF-1 absorbs "slot -1" stores
 constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window slack
 constexpr int CAPP = 16;                               // positions per capture piece
@@ -67,13 +68,15 @@ constexpr int LISTCAP = 256;                           // hits handled per dense
 constexpr int JOBCAP = 32;                             // queued hash re-derivations per flush
 constexpr int REG_LA = 1;
 constexpr int HPC_LA = 2;                              // seed look-ahead (positions) of the Hpc hash loop: 8 spills there
-constexpr int NBL = 32;                                // read starts of a tile kept in LDS (hb / rs); tiles with more search the read table
+constexpr int NBL = 32;                                // read starts of a tile kept in LDS (hb / rs16); tiles with more search the read table
+constexpr int KMAX_FUSED = 32;                         // largest k the fused single-pass emission handles (ring of 64 + k - 1 mixed hashes)
+constexpr int LB_POLL_LIMIT = 1 << 16;                 // look-back polls (~2 us each) before a wave gives up and the host re-runs unfused
 constexpr int STORES_PER_ROUND = 3;                    // vector-memory operations one round of 64 hits issues (j, jend, rid): the counted vmcnt wait relies on it
 constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
 
 struct HpcLds {
-    uint32_t fm[64][5];      // run-head flags of the lane's 144 raw bytes, 32-byte groups, bit 8b+d <-> byte 4d+b
-    uint32_t hbase[64];      // exclusive prefix of per-lane run-head counts
+    uint32_t fm[64][5];      // run-head flags of the lane's 144 raw bytes, natural order: bit i of the 144-bit mask <-> raw byte i
+    uint16_t hbase[64];      // exclusive prefix of per-lane run-head counts (<= 9216)
     uint32_t halo_pos[64];   // tile-relative raw offsets of the run heads that follow the tile
     uint8_t hl[64];          // raw lane that owns run head Tq*q (first head of hash lane q): search hint for the back-map
 };
@@ -82,18 +85,25 @@ struct NoHpcLds {};
 template <bool HPC>
 struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
     uint8_t buf[BUF_BYTES];
-    uint16_t list[LISTCAP];  // validated hits of the current batch: tile-local hash position (bits 0-13), ascending; bit 15 = hash must be re-derived
-    uint16_t jobx[JOBCAP];   // hits whose hash must be re-derived: tile-local position ...
-    uint32_t jobslot[JOBCAP];// ... and record slot (relative to the tile's base)
+    union {
+        struct {
+            uint16_t list[LISTCAP];   // validated hits of the current batch: tile-local hash position (bits 0-13), ascending; bit 15 = hash must be re-derived
+            uint16_t jobx[JOBCAP];    // hits whose hash must be re-derived: tile-local position ...
+            uint16_t jobslot[JOBCAP]; // ... and index of the hit inside the batch
+        };
+        uint64_t ring[64 + KMAX_FUSED]; // fused emission, once the list is dead: mixed hashes of the round's 64 hits behind the k-1 before them
+    };
+    uint32_t hv[LISTCAP];    // fused emission: 32-bit hash of every hit of the batch (written by the listing lanes and the re-derivation)
     int16_t hb[NBL];         // read starts inside the tile, as hash-space positions (ascending; 0 .. TILE_BASES)
-    uint64_t rs[NBL];        // rs[i] = read_off[r0 + i]
+    uint16_t rs16[NBL];      // rs16[i] = read_off[r0 + i] - t0 for the read starts inside the tile (i >= 1; read r0 starts at rs0, kept in a register)
+    int32_t segadj[NBL];     // fused emission, per read segment s of the tile: (windows ending before the segment) - (hits before it) - (hits of the segment that end no window)
+    uint16_t segb[NBL];      // ... and the number of hits before the segment
 };
 constexpr int TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c], l-1)};  OUT table at 2048: {rotl(h[c], l), rotr(rc[c], 1)}
 template <bool HPC>
 constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>); }
-// the hardware allocates LDS in granules: 3 x 54 400 B did NOT fit (the third block of every CU queued behind the other two
-// and the persistent grid ran 13 % longer) although the occupancy query said 3
-static_assert(3 * (block_lds_bytes<true>() + 1024) <= 160 * 1024, "three blocks per CU must fit the 160 KiB LDS with allocation slack");
+// one block of TW = 12 waves per CU: it may use the whole 160 KiB (MI355X_MICROARCH.md: "a single workgroup may declare all 160 KiB")
+static_assert(block_lds_bytes<true>() <= 160 * 1024, "the block of a CU must fit its 160 KiB of LDS");
 
 // inclusive scan over the 64 lanes with DPP row shifts / broadcasts (no LDS round trips)
 __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -577,17 +587,123 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
     raw_e = y_in ? TILE_T * lo2 + decode(w2, n2) : he;
 }
 
-// Dense phase of one tile: hit bitmasks -> validated, ordered minimizer records.  Returns the number of
-// records (tile_cnt) and sets `base` (tile_rec_off).  See the file header for the idea.
-template <int L, bool HPC, class WL, class IssueNext>
+// ------------------------------------------------------------------------------------------------
+// Fused path: what a run of consecutive tiles does to the pair (G, p) -- see TileDesc in s2k_dev.h -- and the look-back
+// that finds a tile's own (G, p) from the descriptors of the tiles before it.
+//   k-min-mers ending in the run = C + (dep ? max(0, m_f - (k-1) + p) : 0);     p after the run = pass ? min(k-1, p + m_f) : q
+// ------------------------------------------------------------------------------------------------
+struct AggF {
+    uint64_t m_f, C, N;
+    uint32_t q;
+    bool dep, pass;
+};
+__device__ __forceinline__ AggF agg_unpack(uint64_t w) {
+    AggF a;
+    a.m_f = w & 0x3FFFu;
+    a.C = (w >> 14) & 0x3FFFu;
+    a.N = (w >> 28) & 0x3FFFu;
+    a.q = (uint32_t)(w >> 42) & 63u;
+    a.dep = ((w >> 48) & 1u) != 0;
+    a.pass = ((w >> 49) & 1u) != 0;
+    return a;
+}
+__device__ __forceinline__ uint64_t agg_windows(const AggF &a, uint32_t p, uint32_t K1) {
+    uint64_t v = a.C;
+    if (a.dep && a.m_f + p > K1) v += a.m_f + p - K1;
+    return v;
+}
+__device__ __forceinline__ uint32_t agg_p(const AggF &a, uint32_t p, uint32_t K1) {
+    if (!a.pass) return a.q;
+    const uint64_t v = a.m_f + p;
+    return v > K1 ? K1 : (uint32_t)v;
+}
+// the run A followed by the run B
+__device__ __forceinline__ AggF agg_then(const AggF &A, const AggF &B, uint32_t K1) {
+    AggF R;
+    R.N = A.N + B.N;
+    if (A.pass) { // A is one stretch of a read that began earlier and goes on: no k-min-mer count of its own yet (C == 0)
+        R.dep = true;
+        R.pass = B.pass;
+        R.m_f = B.dep ? A.m_f + B.m_f : A.m_f; // max(0, a - K1 + p) + max(0, b - K1 + min(K1, p + a)) == max(0, a + b - K1 + p)
+        R.C = B.C;
+        R.q = B.q;
+    } else { // after A, p is the constant A.q
+        R.dep = A.dep;
+        R.pass = false;
+        R.m_f = A.m_f;
+        R.C = A.C + agg_windows(B, A.q, K1);
+        R.q = agg_p(B, A.q, K1);
+    }
+    return R;
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+}
+struct LbState {
+    uint64_t G, Gmn; // k-min-mers / minimizers before the tile
+    uint32_t p;      // min(k-1, minimizers the read that continues into the tile has so far)
+    bool poison, ok; // poison: a tile before this one could not be handled; !ok: gave up waiting
+};
+// Lane i looks at tile hi - i; the nearest tile whose inclusive pair is known ends the walk, the tiles between it and t must
+// have published their own contribution.  A wave waits here only for tiles that other waves are working on right now (tiles
+// are dealt in increasing order and every wave walks its tiles in increasing order, so the smallest unfinished tile never
+// waits); the number of polls is bounded all the same -- a wave that gives up poisons its successors and the host re-runs
+// the call through the two-kernel path.
+__device__ __forceinline__ LbState lookback(const TileDesc *desc, uint64_t t, int lane, uint32_t K1, uint32_t &polls) {
+    AggF suffix{0, 0, 0, 0, true, true}; // tiles (hi, t): nothing yet (the identity)
+    int64_t hi = (int64_t)t - 1;
+    bool poison = false;
+    constexpr unsigned long long M48 = (1ull << 48) - 1ull;
+    for (;;) {
+        const int64_t idx = hi - lane;
+        unsigned long long a = TD_VALID | (3ull << 48), p0 = TD_VALID, p1 = TD_VALID; // before tile 0: G = 0, p = 0
+        if (idx >= 0) {
+            a = __hip_atomic_load(&desc[idx].agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p0 = __hip_atomic_load(&desc[idx].pre0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p1 = __hip_atomic_load(&desc[idx].pre1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint64_t pre_ok = __ballot((p0 & TD_VALID) != 0 && (p1 & TD_VALID) != 0);
+        const uint64_t agg_ok = __ballot((a & TD_VALID) != 0);
+        const int jp = pre_ok ? __builtin_ctzll(pre_ok) : 64;
+        const uint64_t need = jp >= 64 ? ~0ull : ((1ull << jp) - 1ull);
+        if ((agg_ok & need) != need) { // a tile in between has not got that far yet
+            if (++polls > (uint32_t)LB_POLL_LIMIT) return LbState{0, 0, 0, true, false};
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        poison = poison || (__ballot((a & TD_POISON) != 0) & need) != 0;
+        AggF w{0, 0, 0, 0, true, true};
+        for (int i = (jp < 64 ? jp : 64) - 1; i >= 0; i--) w = agg_then(w, agg_unpack(readlane64(a, i)), K1); // earlier tiles first
+        suffix = agg_then(w, suffix, K1);
+        if (jp < 64) {
+            const uint64_t q0 = readlane64(p0, jp), q1 = readlane64(p1, jp);
+            const uint32_t p = (uint32_t)(q0 >> 48) & 63u;
+            return LbState{(q0 & M48) + agg_windows(suffix, p, K1), (q1 & M48) + suffix.N, agg_p(suffix, p, K1),
+                           poison || (q0 & TD_POISON) != 0, true};
+        }
+        hi -= 64;
+    }
+}
+
+// Dense phase of one tile: hit bitmasks -> validated, ordered minimizers.
+//  * FUSED = false: minimizer records (j, jend, hash, read) go to the tile's slab; returns their number and sets `base`
+//    (tile_rec_off); a second kernel (s2k_kminmer.hip) turns them into k-min-mers.
+//  * FUSED = true: the k-min-mers themselves are written, at their final place: every window of k consecutive minimizers that
+//    lies inside the tile (src/lib.rs:231-266, closed form :275-288), at offset G + (windows ending earlier in the tile), G
+//    from the look-back above; km_off of the reads that start in the tile; the tile's first / last k-1 minimizers go to its
+//    edge record, from which fused_fixup_kernel emits the windows that span tiles.
+template <int L, bool HPC, bool FUSED, class WL, class IssueNext>
 __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, const uint8_t *D, const uint2 *tab,
-                                                const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t t,
+                                                const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_tiles, uint64_t t,
                                                 uint64_t t0, uint32_t tile_len, uint32_t nh, uint32_t halo_n,
                                                 uint32_t Tq, uint32_t l, uint32_t r0, uint32_t r1, uint64_t bpos0,
                                                 uint64_t rs0, int lane, const Records &rec, uint64_t *pool_cursor,
-                                                uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem,
+                                                uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem, const Fused &fz,
+                                                bool &dma_waited,
                                                 const uint32_t (&caps)[NPC], const uint32_t (&raw)[5], uint64_t *ph,
                                                 uint64_t &stamp) {
+    uint64_t xacc = 0;     // fused: XOR of the k-min-mer hashes this lane wrote for this tile (whole-run checksum, s2k_counts.xor_hash)
+    uint32_t lb_polls = 0; // fused: look-back polls of this tile (diagnostics)
     // (1) read starts that matter for this tile -> hash-space boundaries HB; an l-mer x is invalid iff
     //     some boundary has HB - w <= x <= HB - 1  (w = l-1 raw positions for Regular: the l-mer must end
     //     before the next read, src/lib.rs:215-230; w = l run heads for Hpc: head x+l must exist in the
@@ -608,7 +724,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     const uint64_t tile_end = t0 + tile_len;
     uint32_t nb = 0;                  // internal boundaries (reads r0+1 .. r0+nb start inside the tile)
     const bool many = (r1 - r0) > (uint32_t)(NBL - 2); // more read starts than the LDS lists hold: generic per-hit lookups
-    if (lane == 0) S.rs[0] = rs0;
+    bool ext_at_end = false;          // a read starts exactly where the tile ends (or the stream ends there)
     {
         uint64_t bpos = bpos0; // read_off[r0 + 1 + lane], fetched ahead; later chunks are loaded here (rare)
         uint64_t chunk_prev = rs0; // start of the read whose end lane 0 holds
@@ -718,10 +834,14 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             }
             if (!many && internal && c0 + lane < (uint32_t)(NBL - 1)) { // remembered for the per-hit read lookup
                 S.hb[c0 + lane] = (int16_t)HB;
-                S.rs[c0 + lane + 1] = bpos;
+                S.rs16[c0 + lane + 1] = (uint16_t)(bpos - t0);
             }
             nb += (uint32_t)__popcll(__ballot(internal));
-            if (em) break;
+            if (em) {
+                const uint64_t ebq = ((uint64_t)bcast((uint32_t)(bpos >> 32), first_ext) << 32) | bcast((uint32_t)bpos, first_ext);
+                ext_at_end = ebq == tile_end;
+                break;
+            }
             const uint64_t ri = (uint64_t)r0 + 1 + c0 + 64 + lane;
             bpos = ri <= n_reads ? read_off[ri] : ~0ull;
             __builtin_amdgcn_s_waitcnt(0x0F70); // as in hpc_compact: nothing pending across the back edge
@@ -733,29 +853,34 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     const uint32_t incl = wave_incl_scan(cnt, lane);
     const uint32_t myoff = incl - cnt;
     const uint32_t N = bcast(incl, 63); // valid minimizers of this tile
-    base = t * rec.slab_cap;
-    if (N == 0) {
-        issue_next(0u, base);
-        return 0;
-    }
-    if (N > rec.slab_cap) { // rare: more hits than the per-tile slab holds
-        uint64_t got = 0;
-        if (lane == 0) got = atomicAdd((unsigned long long *)pool_cursor, (unsigned long long)N);
-        got = ((uint64_t)bcast((uint32_t)(got >> 32), 0) << 32) | bcast((uint32_t)got, 0);
-        base = rec.ovf_base + got;
-        if (base + N > rec.capacity) { // overflow region exhausted: the host re-runs with pool_needed
-            if (lane == 0) {
-                counts->pool_overflow = 1;
-                atomicMax((unsigned long long *)&counts->pool_needed, (unsigned long long)(got + N));
-            }
-            base = 0;
+    base = 0;
+    if constexpr (!FUSED) {
+        base = t * rec.slab_cap;
+        if (N == 0) {
             issue_next(0u, base);
             return 0;
         }
+        if (N > rec.slab_cap) { // rare: more hits than the per-tile slab holds
+            uint64_t got = 0;
+            if (lane == 0) got = atomicAdd((unsigned long long *)pool_cursor, (unsigned long long)N);
+            got = ((uint64_t)bcast((uint32_t)(got >> 32), 0) << 32) | bcast((uint32_t)got, 0);
+            base = rec.ovf_base + got;
+            if (base + N > rec.capacity) { // overflow region exhausted: the host re-runs with pool_needed
+                if (lane == 0) {
+                    counts->pool_overflow = 1;
+                    atomicMax((unsigned long long *)&counts->pool_needed, (unsigned long long)(got + N));
+                }
+                base = 0;
+                issue_next(0u, base);
+                return 0;
+            }
+        }
     }
-    // per-read minimizer counts, once per tile: read r0+i owns the hits in [HB[i-1], HB[i])
+    // per-read minimizer counts, once per tile: read r0+i owns the hits in [HB[i-1], HB[i]) -- lane i keeps the count of
+    // segment i (`mine`) and the number of hits before it (`segstart`)
+    uint32_t mine = 0, segstart = 0;
     if (!many) {
-        uint32_t below_prev = 0, mine = 0;
+        uint32_t below_prev = 0;
         for (uint32_t i = 0; i <= nb; i++) { // wave-uniform trip count
             uint32_t below = N;
             if (i < nb) {
@@ -773,15 +898,111 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                 const int lb = hbi <= 0 ? 0 : ((uint32_t)hbi >= Tq * 64u ? 63 : (int)div_tq((uint32_t)hbi, rcpTq));
                 below = bcast(myoff + c, lb);
             }
-            if ((uint32_t)lane == i) mine = below - below_prev;
+            if ((uint32_t)lane == i) {
+                mine = below - below_prev;
+                segstart = below_prev;
+            }
             below_prev = below;
         }
-        if ((uint32_t)lane <= nb && mine) atomicAdd(&mn_cnt[r0 + lane], mine);
+        if constexpr (!FUSED)
+            if ((uint32_t)lane <= nb && mine) atomicAdd(&mn_cnt[r0 + lane], mine);
+    }
+    // ---- fused: the tile's own contribution to (G, p), published before anything else is done with the hits ---------------
+    const uint32_t K1 = FUSED ? fz.k - 1u : 0u;
+    const bool dep = !(t0 == 0 || rs0 == t0); // a read that began before the tile continues into it
+    uint32_t m_first = 0, m_last = 0, Cfix = 0, q_out = 0, n_head = 0, n_tail = 0;
+    bool pass = false;
+    uint8_t *const edge = FUSED ? fz.edge + t * (uint64_t)edge_stride(fz.k) : nullptr;
+    if constexpr (FUSED) {
+        if (many) { // reads shorter than ~300 bases: this tile is not handled here -- poison what follows, the host re-runs unfused
+            if (lane == 0) {
+                counts->need_unfused = 1;
+                __hip_atomic_store(&fz.desc[t].agg, TD_VALID | TD_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&fz.desc[t].pre0, TD_VALID | TD_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&fz.desc[t].pre1, TD_VALID | TD_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            issue_next(0u, base);
+            return 0;
+        }
+        m_first = bcast(mine, 0);
+        m_last = bcast(mine, (int)nb);
+        uint32_t wfix = (uint32_t)lane <= nb && mine > K1 ? mine - K1 : 0u; // windows of a segment that starts a read in (or at the start of) the tile
+        if (lane == 0 && dep) wfix = 0;                                         // (the first segment's depend on p)
+        Cfix = bcast(wave_incl_scan(wfix, lane), 63);
+        pass = dep && nb == 0 && !ext_at_end;
+        q_out = ext_at_end ? 0u : (m_last < K1 ? m_last : K1);
+        n_head = dep ? (m_first < K1 ? m_first : K1) : 0u;
+        n_tail = ext_at_end ? 0u : (m_last < K1 ? m_last : K1);
+        if (lane == 0)
+            __hip_atomic_store(&fz.desc[t].agg, agg_pack(m_first, Cfix, N, q_out, dep, pass), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // fused: (G, p) of this tile from the look-back, then everything that follows from it: the tile's inclusive pair for its
+    // successors, the edge header, per-segment output offsets, km_off of the reads that start here
+    uint64_t G = 0, Gmn = 0;
+    bool poisoned = false;
+    auto resolve = [&]() {
+        const LbState lb = lookback(fz.desc, t, lane, K1, lb_polls);
+        __builtin_amdgcn_s_waitcnt(0x0F70); // every vector-memory operation so far, the next tile's LDS-DMA loads included, is done
+        dma_waited = true;
+        poisoned = lb.poison || !lb.ok;
+        if (!lb.ok && lane == 0) counts->need_unfused = 1;
+        const uint32_t p_in = dep ? lb.p : 0u;
+        G = lb.G;
+        Gmn = lb.Gmn;
+        const uint32_t skip = lane == 0 ? (dep ? K1 - p_in : K1) : K1; // minimizers of a segment that end no k-min-mer
+        const uint32_t wseg = (uint32_t)lane <= nb && mine > skip ? mine - skip : 0u;
+        const uint32_t winc = wave_incl_scan(wseg, lane);
+        const uint32_t Wb = winc - wseg, Wt = bcast(winc, 63);
+        const uint32_t p_out = pass ? (p_in + m_first < K1 ? p_in + m_first : K1) : q_out;
+        if (lane == 0) {
+            const unsigned long long pz = poisoned ? TD_POISON : 0ull;
+            __hip_atomic_store(&fz.desc[t].pre0, TD_VALID | pz | ((unsigned long long)p_out << 48) | (G + Wt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&fz.desc[t].pre1, TD_VALID | pz | (Gmn + N), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            EdgeHdr h;
+            h.g_excl = G;
+            h.p_in = p_in;
+            h.n_head = n_head;
+            h.n_tail = n_tail;
+            h.flags = pass ? 1u : 0u;
+            h.pad = 0;
+            *reinterpret_cast<EdgeHdr *>(edge) = h;
+        }
+        if ((uint32_t)lane <= nb) {
+            S.segadj[lane] = (int32_t)Wb - (int32_t)segstart - (int32_t)skip;
+            S.segb[lane] = (uint16_t)segstart;
+        }
+        if (!poisoned) {
+            const uint32_t nrd = r1 - r0; // reads r0+1 .. r1 start in (t0, end of the tile]: the first nb inside, the rest exactly at the end
+            if (lane >= 1 && (uint32_t)lane <= nrd) {
+                fz.o_km_off[(uint64_t)r0 + lane] = (uint32_t)lane <= nb ? G + Wb : G + Wt;
+                if (fz.mn_capacity) fz.o_mn_off[(uint64_t)r0 + lane] = (uint32_t)lane <= nb ? Gmn + segstart : Gmn + N;
+            }
+            if (t == 0) // reads 0 .. r0 start at position 0
+                for (uint64_t r = lane; r <= (uint64_t)r0; r += 64) {
+                    fz.o_km_off[r] = 0;
+                    if (fz.mn_capacity) fz.o_mn_off[r] = 0;
+                }
+            if (t + 1 == n_tiles && lane == 0) {
+                fz.o_km_off[n_reads] = G + Wt;
+                if (fz.mn_capacity) fz.o_mn_off[n_reads] = Gmn + N;
+                fz.totals[0] = Gmn + N;
+                fz.totals[1] = G + Wt;
+            }
+        }
+        wave_sync();
+    };
+    if constexpr (FUSED) {
+        if (N == 0) {
+            issue_next(0u, base);
+            resolve();
+            if (lane == 0 && lb_polls) atomicAdd(&counts->lb_polls[t & 63], lb_polls);
+            return 0;
+        }
     }
     uint32_t njobs = 0;
     // Re-derivation of queued hashes (closed form src/nthash_hpc.rs:144,168): FOUR lanes per job, each takes a quarter of the l
     // bases (two LDS round trips per pass of 16 jobs instead of eight per lane), partial hashes are XOR-ed across the quad by DPP.
-    auto flush_jobs = [&]() {
+    auto flush_jobs = [&](uint32_t b0) {
         wave_sync();
         const uint32_t part = (uint32_t)lane & 3u;
         const uint32_t per = (l + 3u) >> 2;          // bases per lane
@@ -828,19 +1049,27 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             r ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0xB1, 0xf, 0xf, false);
             f ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x4E, 0xf, 0xf, false);
             r ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x4E, 0xf, 0xf, false);
-            if (act && part == 0) rec.hash[base + S.jobslot[job]] = f < r ? f : r;
+            if (act && part == 0) {
+                if constexpr (FUSED) S.hv[S.jobslot[job] - b0] = f < r ? f : r;
+                else rec.hash[base + S.jobslot[job]] = f < r ? f : r;
+            }
         }
         njobs = 0;
         wave_sync();
     };
+    bool resolved = false;          // fused: the look-back has been done (once per tile, as late as possible)
+    uint32_t jprev = 0;             // fused: j of the hits of the previous round of 64 (window starts reach back k-1 hits)
+    uint64_t xcarry = 0;            // fused: mixed hashes of the last k-1 hits of the previous batch (lanes 0 .. k-2)
     // (3) batches of up to LISTCAP hits: lanes list their own hits (ascending), then every lane takes one hit.
     //     No global LOADS in here: a load would make the compiler drain the previous round's stores.
-    for (uint32_t b0 = 0; b0 < N; b0 += LISTCAP) {
+    // A tile with at most LISTCAP hits (all but low-complexity sequence) takes its own instantiation of the batch: no range test
+    // in the listing, and the hit masks and kept hashes (19 registers) are dead once the hits are listed -- inside the loop
+    // of the general case they stay live through the rounds for the next batch.
+    auto batch = [&](uint32_t b0, auto single_c) {
+        constexpr bool SINGLE = decltype(single_c)::value;
         wave_sync();
-        // every lane lists its own hits and stores the kept hash of those that were the last raw hit of their piece; a tile
-        // with at most LISTCAP hits (all but low-complexity sequence) takes the instantiation without the batch-range test
-        auto list_hits = [&](auto single_c) {
-            constexpr bool SINGLE = decltype(single_c)::value;
+        // every lane lists its own hits and stores the kept hash of those that were the last raw hit of their piece
+        auto list_hits = [&]() {
             uint32_t k = myoff;
 #pragma unroll
             for (int d = 0; d < 5; d++) {
@@ -855,14 +1084,17 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                     const uint32_t hvk = (bit & 16) ? cap_hi : cap_lo;
                     if (SINGLE || (k >= b0 && k < b0 + LISTCAP)) {
                         S.list[k - b0] = (uint16_t)((Tq * lane + 32 * d + bit) | (later ? 0x8000u : 0u));
-                        if (!later && !(sem.dbg_skip & 16)) rec.hash[base + k] = hvk;
+                        if constexpr (FUSED) {
+                            S.hv[k - b0] = hvk; // (a re-derived hash overwrites it below)
+                        } else {
+                            if (!later && !(sem.dbg_skip & 16)) rec.hash[base + k] = hvk;
+                        }
                     }
                     k++;
                 }
             }
         };
-        if (N <= (uint32_t)LISTCAP) list_hits(std::true_type{});
-        else list_hits(std::false_type{});
+        list_hits();
         wave_sync();
         S2K_STAMP(4); // scan + list
         const uint32_t bn = N - b0 < (uint32_t)LISTCAP ? N - b0 : (uint32_t)LISTCAP;
@@ -881,99 +1113,84 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             while (jobs) { // wave-uniform: queue up to JOBCAP jobs, flush, queue the rest
                 const uint32_t room = (uint32_t)JOBCAP - njobs;
                 const uint32_t rank = (uint32_t)__popcll(jobs & ((1ull << lane) - 1ull));
-                const bool mine = need && ((jobs >> lane) & 1ull) && rank < room;
-                if (mine) {
+                const bool minej = need && ((jobs >> lane) & 1ull) && rank < room;
+                if (minej) {
                     S.jobx[njobs + rank] = (uint16_t)(e & 0x3FFFu);
-                    S.jobslot[njobs + rank] = b0 + kq;
+                    S.jobslot[njobs + rank] = (uint16_t)(b0 + kq);
                 }
-                const uint64_t done = __ballot(mine);
+                const uint64_t done = __ballot(minej);
                 njobs += (uint32_t)__popcll(done);
                 jobs &= ~done;
-                if (jobs) flush_jobs();
+                if (jobs) flush_jobs(b0);
             }
         }
-        if (njobs) flush_jobs();
+        if (njobs) flush_jobs(b0);
         S2K_STAMP(12); // hash re-derivation
         if (b0 + (uint32_t)LISTCAP >= N) issue_next(N, base);
+        // one hit per lane: tile-local hash position -> stream positions of the l-mer's first base and of the last base that belongs
+        // to it, and the read it lies in (number of read starts at or before it, among those kept in LDS)
+        auto backmap = [&](uint32_t x, uint64_t &p, uint64_t &e1) {
+            if constexpr (HPC) {
+                uint32_t rp = 0, re = 0;
+                // Hpc: st[p+l] - 1 (src/nthash_hpc.rs:281; head x + l exists: the hit survived validation);
+                // HpcSimd: st[p+l-1], the start of the last run (src/nthash_hpc_simd.rs:64)
+                const uint32_t back = sem.end_kind == 2 ? 1u : 0u;
+                hpc_rawpos2(S, x, l - back, nh, halo_n, Tq, rcpTq, rp, re);
+                e1 = t0 + re - (1u - back);
+                p = t0 + rp;
+            } else {
+                p = t0 + x;
+                e1 = p + l - 1; // src/lib.rs:226
+            }
+        };
+        if constexpr (!FUSED) {
         auto rounds = [&](auto many_c) {
         constexpr bool MANY = decltype(many_c)::value;
-        constexpr int U = 1; // hits per lane per iteration (two overlapped back-maps cost ~25 VGPRs: three waves per SIMD matter more)
-        for (uint32_t k0 = 0; k0 < bn; k0 += 64 * U) {
+        for (uint32_t k0 = 0; k0 < bn; k0 += 64) {
             // (markers for tools/isa/check_vmcnt.py: the loop body must issue the STORES_PER_ROUND vector-memory operations the
             // counted wait at the top of the next tile relies on)
             asm volatile("; S2K_MARK round_begin many=%0" ::"i"(MANY ? 1 : 0));
-            uint32_t kk[U], x[U], rid[U];
-            bool act[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                kk[u] = k0 + 64 * u + lane;
-                act[u] = kk[u] < bn;
-                x[u] = rid[u] = 0;
-                if (act[u]) {
-                    const uint32_t e = S.list[kk[u]];
-                    x[u] = e & 0x3FFFu;
-                }
-            }
+            const uint32_t kk = k0 + lane;
+            const bool act = kk < bn;
+            uint32_t x = 0, rid = 0;
+            if (act) x = S.list[kk] & 0x3FFFu;
             S2K_STAMP(8); // round: list read
-            uint64_t p[U], e1[U]; // stream position of the l-mer start; position of the last base that belongs to it
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                p[u] = e1[u] = 0;
-                if (act[u]) {
-                    if constexpr (HPC) {
-                        uint32_t rp = 0, re = 0;
-                        // Hpc: st[p+l] - 1 (src/nthash_hpc.rs:281; head x + l exists: the hit survived validation);
-                        // HpcSimd: st[p+l-1], the start of the last run (src/nthash_hpc_simd.rs:64)
-                        const uint32_t back = sem.end_kind == 2 ? 1u : 0u;
-                        hpc_rawpos2(S, x[u], l - back, nh, halo_n, Tq, rcpTq, rp, re);
-                        e1[u] = t0 + re - (1u - back);
-                        p[u] = t0 + rp;
-                    } else {
-                        p[u] = t0 + x[u];
-                        e1[u] = p[u] + l - 1; // src/lib.rs:226
-                    }
-                }
-            }
+            uint64_t p = 0, e1 = 0; // stream position of the l-mer start; position of the last base that belongs to it
+            if (act) backmap(x, p, e1);
             S2K_STAMP(9); // round: back-map
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (act[u]) {
-                    uint64_t rstart;
-                    if constexpr (!MANY) {
-                        uint32_t c = 0;
-                        for (uint32_t i = 0; i < nb; i++) c += (S.hb[i] <= (int32_t)x[u]); // wave-uniform trip count, LDS broadcast
-                        rid[u] = r0 + c;
-                        rstart = S.rs[c];
-                    } else { // > NBL - 2 reads start in this tile: search the read table itself
-                        uint32_t lo = r0, hi = r1;
-                        while (lo < hi) {
-                            uint32_t mid = lo + (hi - lo + 1) / 2;
-                            if (read_off[mid] <= p[u]) lo = mid;
-                            else hi = mid - 1;
-                        }
-                        rid[u] = lo;
-                        rstart = read_off[lo];
+            if (act) {
+                uint64_t rstart;
+                if constexpr (!MANY) {
+                    uint32_t c = 0;
+                    for (uint32_t i = 0; i < nb; i++) c += (S.hb[i] <= (int32_t)x); // wave-uniform trip count, LDS broadcast
+                    rid = r0 + c;
+                    rstart = c == 0 ? rs0 : t0 + S.rs16[c];
+                } else { // > NBL - 2 reads start in this tile: search the read table itself
+                    uint32_t lo = r0, hi = r1;
+                    while (lo < hi) {
+                        uint32_t mid = lo + (hi - lo + 1) / 2;
+                        if (read_off[mid] <= p) lo = mid;
+                        else hi = mid - 1;
                     }
-                    const uint64_t slot = base + b0 + kk[u];
-                    if (!(sem.dbg_skip & 16)) {
-                        rec.j[slot] = (uint32_t)(p[u] - rstart);
-                        rec.jend[slot] = (uint32_t)(e1[u] - rstart);
-                        rec.rid[slot] = rid[u];
-                    }
+                    rid = lo;
+                    rstart = read_off[lo];
+                }
+                const uint64_t slot = base + b0 + kk;
+                if (!(sem.dbg_skip & 16)) {
+                    rec.j[slot] = (uint32_t)(p - rstart);
+                    rec.jend[slot] = (uint32_t)(e1 - rstart);
+                    rec.rid[slot] = rid;
                 }
             }
             S2K_STAMP(10); // round: read lookup + stores
             if constexpr (MANY) { // per-read minimizer counts: one atomic per (round, read); the common case is counted per tile above
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    uint64_t remm = __ballot(act[u]);
-                    while (remm) {
-                        const int z = __builtin_ctzll(remm);
-                        const uint32_t rz = bcast(rid[u], z);
-                        const uint64_t same = __ballot(act[u] && rid[u] == rz);
-                        if (lane == z) atomicAdd(&mn_cnt[rz], (uint32_t)__popcll(same));
-                        remm &= ~same;
-                    }
+                uint64_t remm = __ballot(act);
+                while (remm) {
+                    const int z = __builtin_ctzll(remm);
+                    const uint32_t rz = bcast(rid, z);
+                    const uint64_t same = __ballot(act && rid == rz);
+                    if (lane == z) atomicAdd(&mn_cnt[rz], (uint32_t)__popcll(same));
+                    remm &= ~same;
                 }
             }
             asm volatile("; S2K_MARK round_end many=%0" ::"i"(MANY ? 1 : 0));
@@ -983,6 +1200,109 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
         // separate instantiation keeps its global loads out of the common loop
         if (many) rounds(std::true_type{});
         else rounds(std::false_type{});
+        } else {
+        // ---- fused: back-map rounds into registers, look-back, emission rounds --------------------------------------------
+        constexpr int NR = LISTCAP / 64;
+        uint32_t jv[NR], je[NR], cs[NR];
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            jv[u] = je[u] = cs[u] = 0;
+            if (64u * u < bn) { // wave-uniform
+                const uint32_t kq = 64u * u + lane;
+                const bool act = kq < bn;
+                if (act) {
+                    const uint32_t x = S.list[kq] & 0x3FFFu;
+                    uint64_t p = 0, e1 = 0;
+                    backmap(x, p, e1);
+                    uint32_t c = 0;
+                    for (uint32_t i = 0; i < nb; i++) c += (S.hb[i] <= (int32_t)x); // wave-uniform trip count, LDS broadcast
+                    const uint64_t rstart = c == 0 ? rs0 : t0 + S.rs16[c];
+                    jv[u] = (uint32_t)(p - rstart);
+                    je[u] = (uint32_t)(e1 - rstart);
+                    cs[u] = c;
+                    // the tile's first / last k-1 minimizers, for the k-min-mers that span tiles (fused_fixup_kernel)
+                    const uint32_t i = b0 + kq;
+                    if (i < n_head) reinterpret_cast<EdgeRec *>(edge + sizeof(EdgeHdr))[i] = EdgeRec{S.hv[kq], je[u]};
+                    if (i + n_tail >= N) reinterpret_cast<EdgeRec *>(edge + sizeof(EdgeHdr))[K1 + (i + n_tail - N)] = EdgeRec{S.hv[kq], jv[u]};
+                }
+            }
+        }
+        S2K_STAMP(9); // back-map rounds
+        if (!resolved) {
+            resolve();
+            resolved = true;
+        }
+        S2K_STAMP(10); // look-back
+        if (!poisoned) {
+            const uint32_t k = fz.k;
+            if constexpr (!SINGLE)
+                if (b0 != 0 && (uint32_t)lane < K1) S.ring[lane] = xcarry; // (the list of this batch sat on the ring meanwhile)
+#pragma unroll
+            for (int u = 0; u < NR; u++) {
+                if (64u * u < bn) { // wave-uniform
+                    const uint32_t kq = 64u * u + lane;
+                    const bool act = kq < bn;
+                    const uint32_t i = b0 + kq; // index of the hit among the tile's minimizers
+                    const uint32_t h32 = act ? S.hv[kq] : 0u;
+                    const uint64_t xm = mix32(h32); // src/lib.rs:157-169
+                    wave_sync();
+                    S.ring[K1 + lane] = xm;
+                    wave_sync();
+                    const uint32_t sb = S.segb[cs[u]];
+                    const int32_t adj = S.segadj[cs[u]];
+                    // the window of k minimizers that ENDS at this hit lies inside the tile (and inside the read)
+                    const bool win = act && i - sb >= K1;
+                    uint64_t f = 0, r = 0;
+                    for (uint32_t m = 0; m < k; m++) { // ring[lane + m] = hit i - (k-1) + m
+                        const uint64_t xw = S.ring[lane + m];
+                        f = ((f << 1) | (f >> 63)) ^ xw; // F  = XOR rotl(x_m, k-1-m)   (src/lib.rs:238-249, closed form :275-288)
+                        r = ((r >> 1) | (r << 63)) ^ xw; // Rv = rotl(XOR rotr(x_m, k-1-m), k-1) = XOR rotl(x_m, m)
+                    }
+                    const uint64_t rvv = rotl64(r, K1);
+                    // start = j of the window's first minimizer: k-1 hits back, in this round or the one before it
+                    const uint32_t jsame = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - K1) & 63u) << 2, (int)jv[u]);
+                    const uint32_t jbefore = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - K1) & 63u) << 2, (int)jprev);
+                    const uint32_t jstart = (uint32_t)lane >= K1 ? jsame : jbefore;
+                    const uint64_t hmin = f < rvv ? f : rvv;
+                    if (win) {
+                        const uint64_t o = G + (uint64_t)(int64_t)((int32_t)i + adj);
+                        xacc ^= hmin;
+                        if (o < fz.km_capacity) {
+                            if (fz.o_hash) fz.o_hash[o] = hmin;
+                            if (fz.o_start) fz.o_start[o] = jstart;
+                            if (fz.o_end) fz.o_end[o] = je[u];
+                            if (fz.o_rev) fz.o_rev[o] = (uint8_t)(rvv < f); // src/lib.rs:250-251
+                        }
+                    }
+                    if (fz.mn_capacity && act) { // optional minimizer triples (NtHashHPCIterator::Item, src/nthash_hpc.rs:193)
+                        const uint64_t g = Gmn + i;
+                        if (g < fz.mn_capacity) {
+                            fz.o_mn_j[g] = jv[u];
+                            fz.o_mn_jend[g] = je[u];
+                            fz.o_mn_hash[g] = h32;
+                        }
+                    }
+                    wave_sync();
+                    if ((uint32_t)lane >= 64u - K1) S.ring[lane - (64u - K1)] = xm; // the last k-1 hits of a full round lead the next one
+                    jprev = jv[u];
+                }
+            }
+            if constexpr (!SINGLE) {
+                wave_sync();
+                if ((uint32_t)lane < K1) xcarry = S.ring[lane];
+            }
+        }
+        }
+    };
+    if (N <= (uint32_t)LISTCAP) batch(0u, std::true_type{});
+    else
+        for (uint32_t b0 = 0; b0 < N; b0 += LISTCAP) batch(b0, std::false_type{});
+    if constexpr (FUSED) { // one atomic per tile into one of 4096 shards
+        for (int o = 32; o > 0; o >>= 1) xacc ^= __shfl_xor(xacc, o);
+        if (lane == 0) {
+            if (xacc) atomicXor((unsigned long long *)&fz.xor_shards[t & (XOR_SHARDS - 1)], (unsigned long long)xacc);
+            if (lb_polls) atomicAdd(&counts->lb_polls[t & 63], lb_polls);
+        }
     }
     return N;
 }
@@ -991,16 +1311,20 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
 // While the rounds of a tile run, the next tile's 9344 bytes are in flight into the wave's LDS buffer (LDS-DMA), and the
 // read-table entries of the next tiles are fetched before they are needed, so no global-load latency sits on the critical
 // path except in the first iteration.
-template <int L, bool HPC>
+// FUSED: the k-min-mers are written by this kernel (see dense_phase); the look-back needs every tile below a tile that is
+// being processed to be in some running wave's hands or finished: tiles are handed out in increasing order (the static three,
+// then the cursors, which a wave never changes) and the grid is exactly what is resident at once.
+template <int L, bool HPC, bool FUSED>
 __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
     uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
-    uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts) {
+    uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts, const Fused *fzp) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     using WL = WaveLdsT<HPC>;
     uint2 *tab = reinterpret_cast<uint2 *>(smem);
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap(); // lut() assumes it
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: everything per tile is scalar
+    const int lane0 = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: everything per tile is scalar
+    int lane = lane0; // re-made opaque at the top of every tile (see the loop): nothing derived from the lane index is loop-invariant
     const uint32_t l = L > 0 ? (uint32_t)L : sem.l;
     for (int c = threadIdx.x; c < 256; c += 64 * TW) {
         uint32_t cc = c;
@@ -1082,28 +1406,20 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     // that wait -- every other load of the next tile's data is issued before the hash loop and waited for right after it --
     // and the wait leaves exactly that many operations in flight.
     uint32_t stores_after_dma = 0;
+    // FUSED: no counting -- the look-back of every tile ends in a full s_waitcnt vmcnt(0) that comes after the DMA loads were
+    // issued (dma_waited), so at the top of the next iteration they have landed; the k-min-mer stores issued after it are never
+    // waited for.  Only a tile whose loads went out after its look-back (more than LISTCAP hits) waits at the top.
+    bool dma_waited = false; // wave-uniform
     // tn / tnn: the next two tiles of this wave; >= n_tiles: none.  Dynamic tiles are numbered from dyn0 on: cursor g deals
     // dyn0 + g, dyn0 + g + TILE_CURSORS, ... (pool_cursor[16 + 16 g], zeroed by the host before the launch).
     uint64_t tn = t + n_waves, tnn = t + 2 * n_waves;
     const uint64_t dyn0 = 3 * n_waves;
-    uint32_t cur_g = (uint32_t)((blockIdx.x * TW + w) % TILE_CURSORS);
+    const uint32_t cur_g = (uint32_t)((blockIdx.x * TW + w) % TILE_CURSORS);
     unsigned int *const cursors = (unsigned int *)(pool_cursor + 16); // 32-bit draws (a 64-bit result's dead upper half would be
                                                                        // reused early and pull a vmcnt(0) in front of the compaction); cursor g = word 32 g
-    // the cursor this wave draws from is dry: look at all of them, move to the next one (cyclically) that is not, draw there
-    auto draw_elsewhere = [&]() -> uint64_t {
-        for (;;) {
-            const uint64_t left_g = dyn0 + (uint64_t)lane < n_tiles ? (n_tiles - dyn0 - lane + TILE_CURSORS - 1) / TILE_CURSORS : 0; // tiles cursor `lane` deals
-            const uint64_t seen = __hip_atomic_load(&cursors[32 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint64_t open = __ballot(seen < left_g);
-            if (!open) return ~0ull;
-            const uint64_t after = open & ~((2ull << cur_g) - 1ull);
-            cur_g = (uint32_t)__builtin_ctzll(after ? after : open);
-            unsigned int got = 0;
-            if (lane == 0) got = atomicAdd(&cursors[32 * cur_g], 1u);
-            const uint64_t tile = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            if (tile < n_tiles) return tile;
-        }
-    };
+    // (A wave stays with its cursor: when that runs dry the wave is done.  Moving on to another cursor -- round 2 did, for the
+    // last fraction of a percent of balance at the end of the kernel -- could hand a wave a tile BELOW one it already holds, and
+    // the fused path's look-back relies on every wave walking its tiles in increasing order.)
     uint32_t r0n = 0, r1n = 0;
     if (tn < n_tiles) {
         r0n = tile_read0[tn];
@@ -1111,6 +1427,12 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     }
 
     for (; t < n_tiles;) {
+        // A dozen values derived from the lane index (64-bit zero-extensions, 16 x lane offsets, masks) are loop-invariant; LLVM
+        // hoists them out of this loop and then holds -- or spills -- them across the hash loop, where the register pressure
+        // peaks (the kernels lost 20-55 VGPRs that way).  An opaque copy per tile makes it recompute the two or three
+        // instructions each where they are used.
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
         const uint64_t t0 = t * (uint64_t)TILE_BASES;
         const uint64_t rem = n_bases - t0;
         const uint32_t avail = rem > (uint64_t)(TILE_BASES + 128) ? (uint32_t)(TILE_BASES + 128) : (uint32_t)rem;
@@ -1120,6 +1442,9 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         if (__builtin_amdgcn_readfirstlane((int)have_pre)) { // a scalar branch: as a divergent if/else the slow path's loads would precede this wait
             // loaded into the buffer by the previous iteration (prologue: just now): wait for the loads, nothing to move.
             // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; 0x0F70 = vmcnt(0) only
+            if constexpr (FUSED) {
+                if (!dma_waited) __builtin_amdgcn_s_waitcnt(0x0F70);
+            } else {
             static_assert(STORES_PER_ROUND == 3, "the cases below are 1 .. 4 rounds of STORES_PER_ROUND operations");
             asm volatile("; S2K_MARK counted_wait per_round=%0" ::"i"(STORES_PER_ROUND));
             switch (__builtin_amdgcn_readfirstlane((int)stores_after_dma)) { // wave-uniform, and the compiler should know
@@ -1129,12 +1454,16 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
                 case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
                 default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
             }
+            }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         } else { // tile at the end of the stream: guarded loads, zero past the end
             const uint8_t *g = bases + t0;
+            uint32_t l16o = l16_tile;
+            asm volatile("" : "+v"(l16o)); // opaque: or the ten per-lane addresses of this rare path are hoisted out of the tile loop
+                                            // and held (then spilled) across the hash loop
             for (int r = 0; r < NPRE; r++) {
-                const uint32_t off = l16_tile + 1024 * r;
+                const uint32_t off = l16o + 1024 * r;
                 if (r == NPRE - 1 && lane >= 8) break;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (off + 16 <= avail) {
@@ -1195,10 +1524,13 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         S2K_STAMP(1); // hpc compaction
         // ---- the next tile's bases: DMA into this wave's buffer, issued from inside the dense phase (see issue_once) -----
         auto issue_next = [&](uint32_t n_rec, uint64_t rec_base) {
-            if (lane == 0) { // before the DMA loads: only the rounds' stores may follow them
-                tile_cnt[t] = n_rec;
-                tile_rec_off[t] = rec_base;
+            if constexpr (!FUSED) {
+                if (lane == 0) { // before the DMA loads: only the rounds' stores may follow them
+                    tile_cnt[t] = n_rec;
+                    tile_rec_off[t] = rec_base;
+                }
             }
+            dma_waited = false;
             have_pre = false;
             if (tn < n_tiles && is_full(tn)) {
                 prefetch(tn);
@@ -1240,11 +1572,31 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
             if (!issued) issue_next(n_rec, rec_base);
             issued = true;
         };
-        if (nh != 0 && sem.enabled) {
+        // fused: the ~30 words of output pointers and capacities are read from memory HERE, once per tile (scalar loads), instead of
+        // being kernel arguments that live in SGPRs across the hash loop (they cost 26 spilled VGPRs there)
+        // The dense phase gets its OWN copy of the lane index, opaque to the compiler: everything it derives from the lane (a dozen
+        // masks, offsets and 64-bit zero-extensions) is otherwise loop-invariant, gets hoisted out of the tile loop and lives --
+        // or is spilled -- across the hash loop, which is where the register pressure peaks.
+        int lane_d = lane;
+        asm volatile("" : "+v"(lane_d));
+        Fused fz{};
+        if constexpr (FUSED) {
+            // (through the constant address space: scalar loads; as ordinary global loads they land in VGPRs and get spilled)
+            typedef const __attribute__((address_space(4))) unsigned long long *c64_p;
+            c64_p fq = (c64_p)(uintptr_t)fzp;
+            asm volatile("" : "+s"(fq)); // opaque: keeps the loads from being hoisted out of the tile loop
+            static_assert(sizeof(Fused) % 8 == 0, "copied as 64-bit words");
+            unsigned long long fw[sizeof(Fused) / 8];
+#pragma unroll
+            for (size_t i = 0; i < sizeof(Fused) / 8; i++) fw[i] = fq[i];
+            __builtin_memcpy(&fz, fw, sizeof fz);
+        }
+        if (FUSED || (nh != 0 && sem.enabled)) { // (fused: every tile takes part in the look-back chain, hits or not)
 #ifndef EXP_NODENSE
             if (!(sem.dbg_skip & 2))
-                N = dense_phase<L, HPC>(issue_once, S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1, bpos0,
-                                     rs0, lane, rec, pool_cursor, mn_cnt, counts, base, sem, caps, raw, ph, stamp);
+                N = dense_phase<L, HPC, FUSED>(issue_once, S, D, tab, read_off, n_reads, n_tiles, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1,
+                                            bpos0, rs0, lane_d, rec, pool_cursor, mn_cnt, counts, base, sem, fz, dma_waited,
+                                            caps, raw, ph, stamp);
 #endif
             S2K_STAMP(5); // rounds
         }
@@ -1260,10 +1612,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; prevb = prevbn; // rotate the pipeline
         t = tn;
         tn = tnn;
-        if (tnn < n_tiles) {
-            tnn = drawn;
-            if (tnn >= n_tiles) tnn = draw_elsewhere();
-        }
+        if (tnn < n_tiles) tnn = drawn; // >= n_tiles: this wave's cursor has run dry
         S2K_STAMP(6); // tail
     }
 #ifdef S2K_PROFILE
@@ -1302,11 +1651,11 @@ __global__ __launch_bounds__(256) void tile_index_kernel(const uint64_t *__restr
     tile_read0[t] = (uint32_t)lo;
 }
 
-template <int L, bool HPC>
+template <int L, bool HPC, bool FUSED>
 hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                            uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
-                           uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts) {
-    auto kern = tile_minimizer_kernel<L, HPC>;
+                           uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts, const Fused *d_fz) {
+    auto kern = tile_minimizer_kernel<L, HPC, FUSED>;
     const int lds = block_lds_bytes<HPC>();
     // per instantiation AND per device: function attributes and occupancy belong to the device the module is loaded on
     // (contexts on different threads may launch concurrently: the cache is filled under a lock)
@@ -1323,9 +1672,9 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
         S2K_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         int occ = 0;
         S2K_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64 * TW, lds));
-        // The occupancy query ignores the granule LDS is allocated in: it answered 3 for 3 x 54 400 B of a 163 840 B LDS, the
-        // hardware kept two blocks per CU resident and the third queued behind them (+13 % kernel time).  Trust it only up to
-        // what fits with every block rounded up to 2 KiB.
+        // The occupancy query ignores the granule LDS is allocated in (round 2: it answered 3 for 3 x 54 400 B of a 163 840 B
+        // LDS, two blocks were resident and the third queued behind them).  Trust it only up to what fits with every block rounded
+        // up to 2 KiB -- with one 12-wave block per CU that is 1.
         const int fit = (int)((size_t)prop.sharedMemPerMultiprocessor / (((size_t)lds + 2047) & ~(size_t)2047));
         if (fit >= 1 && occ > fit) occ = fit;
         per_cu_d[dev] = occ < 1 ? 1 : occ;
@@ -1339,7 +1688,7 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
     const uint64_t resident = (uint64_t)n_cu * per_cu;
     if (blocks > resident) blocks = resident; // persistent: waves loop over the remaining tiles
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * TW), lds, st, bases, read_off, n_reads, n_bases, n_tiles,
-                       tile_read0, sem, rec, pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts);
+                       tile_read0, sem, rec, pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts, d_fz);
     return hipGetLastError();
 }
 
@@ -1347,12 +1696,13 @@ template <int L>
 hipError_t launch_tiles_l(bool hpc, hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
                           uint64_t n_bases, uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec,
                           uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
-                          Counts *counts) {
-    if (hpc)
-        return launch_tiles_lh<L, true>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
-                                        tile_rec_off, tile_cnt, mn_cnt, counts);
-    return launch_tiles_lh<L, false>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
-                                     tile_rec_off, tile_cnt, mn_cnt, counts);
+                          Counts *counts, const Fused *d_fused) {
+#define S2K_GO(H, F)                                                                                                       \
+    launch_tiles_lh<L, H, F>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, tile_rec_off, \
+                             tile_cnt, mn_cnt, counts, d_fused)
+    if (d_fused) return hpc ? S2K_GO(true, true) : S2K_GO(false, true);
+    return hpc ? S2K_GO(true, false) : S2K_GO(false, false);
+#undef S2K_GO
 }
 
 } // namespace

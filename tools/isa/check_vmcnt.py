@@ -35,8 +35,9 @@ def check(path):
     if not funcs:
         errors.append("%s: no tile_minimizer_kernel instantiation found" % path)
     for name, a, b in funcs:
-        short = re.search(r"tile_minimizer_kernelILi(\d+)ELb(\d)", name)
-        tag = "L=%s hpc=%s" % (short.group(1), short.group(2)) if short else name
+        short = re.search(r"tile_minimizer_kernelILi(\d+)ELb(\d)ELb(\d)", name)
+        tag = "L=%s hpc=%s fused=%s" % short.groups() if short else name
+        fused = bool(short) and short.group(3) == "1"
         labels, branches, marks, need, dma, waits = {}, [], [], None, 0, set()
         for i in range(a, b):
             s = lines[i].strip()
@@ -57,6 +58,15 @@ def check(path):
             m = re.match(r"s_waitcnt vmcnt\((\d+)\)$", s)
             if m:
                 waits.add(int(m.group(1)))
+        if fused:
+            # the fused kernel counts nothing: its look-back ends in a full s_waitcnt vmcnt(0) after the DMA loads were issued, and
+            # the top of the next tile waits in full when that did not happen (dma_waited)
+            if need is not None or marks:
+                errors.append("%s: a counted wait in the fused kernel" % tag)
+            if dma < 10 or 0 not in waits:
+                errors.append("%s: %d LDS-DMA loads / no full vmcnt wait" % (tag, dma))
+            report.append("%s: no counted wait (full s_waitcnt vmcnt(0) after the look-back), %d LDS-DMA loads" % (tag, dma))
+            continue
         if need is None:
             errors.append("%s: no counted_wait marker" % tag)
             continue
