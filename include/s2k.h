@@ -63,7 +63,8 @@ typedef enum s2k_mode {
 enum {
     S2K_FLAG_WANT_MINIMIZERS = 1u << 0, /* also return the (j, jend, hash32) triples (NtHashHPCIterator::Item, src/nthash_hpc.rs:193) */
     S2K_FLAG_FORCE_SERIAL = 1u << 1,    /* use the read-serial kernels (exact for every input; slow) instead of the tiled ones */
-    S2K_FLAG_NO_PACK2 = 1u << 2         /* s2k_extract, s2k_run_file: send the text as it is instead of 2-bit packed (+ exception list) over PCIe */
+    S2K_FLAG_NO_PACK2 = 1u << 2,        /* s2k_extract, s2k_run_file: send the text as it is instead of 2-bit packed (+ exception list) over PCIe */
+    S2K_FLAG_NO_FUSED = 1u << 3         /* tiled kernel + separate k-min-mer kernel (counts.path 2) instead of the single pass that writes the k-min-mers itself */
 };
 
 typedef struct s2k_params {

@@ -321,6 +321,8 @@ s2k_status enqueue(s2k_ctx *ctx) {
     const bool fused = !c.serial && !c.no_fused && n_tiles >= 1 && n_reads >= 1 && c.sem.k <= 32;
     c.fused_run = fused;
     TileDesc *desc = nullptr;
+    GroupDesc *gdesc = nullptr;
+    const uint64_t n_groups = (n_tiles + TILE_GROUP - 1) / TILE_GROUP;
     uint8_t *edge = nullptr;
     uint64_t *totals = nullptr;
     Fused *d_fz = nullptr;
@@ -348,6 +350,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
         }
         if (fused) {
             desc = a.take<TileDesc>(n_tiles);
+            gdesc = a.take<GroupDesc>(n_groups);
             edge = a.take<uint8_t>(n_tiles * (uint64_t)edge_stride(c.sem.k));
             totals = a.take<uint64_t>(2);
             d_fz = a.take<Fused>(1);
@@ -411,6 +414,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
         if (fused) {
             Fused fz{};
             fz.desc = desc;
+            fz.gdesc = gdesc;
             fz.edge = edge;
             fz.k = c.sem.k;
             fz.km_capacity = o.km_capacity;
@@ -427,6 +431,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
             fz.xor_shards = (unsigned long long *)ctx->d_xor;
             fz.totals = (unsigned long long *)totals;
             S2K_TRY(hipMemsetAsync(desc, 0, n_tiles * sizeof(TileDesc), st), "memset tile descriptors");
+            S2K_TRY(hipMemsetAsync(gdesc, 0, n_groups * sizeof(GroupDesc), st), "memset group descriptors");
             if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
             S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, nullptr,
                                            nullptr, nullptr, ctx->d_counts, &fz, d_fz, st),
@@ -521,6 +526,15 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
                 fprintf(stderr, " %llu", sum);
             }
             fprintf(stderr, "\n");
+        }
+        {
+            static const bool dbg_lb = getenv("S2K_DEBUG_LB") != nullptr; // diagnostics of the fused path's look-back (stderr)
+            if (dbg_lb && c.fused_run) {
+                unsigned long long polls = 0;
+                for (int i = 0; i < 64; i++) polls += h->lb_polls[i];
+                const uint64_t nt = (c.n_bases + TILE_BASES - 1) / TILE_BASES;
+                fprintf(stderr, "[s2k lb] tiles %llu look-back polls %llu (%.2f per tile)\n", (unsigned long long)nt, polls, nt ? (double)polls / (double)nt : 0.0);
+            }
         }
         if (counts) memcpy(counts, h, sizeof(s2k_counts));
         ctx->pending_status = (h->km_overflow || h->mn_overflow) ? S2K_ERR_CAPACITY : S2K_OK;
@@ -699,6 +713,7 @@ s2k_status s2k_extract_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64
     if (const char *dbg = getenv("S2K_DEBUG_SKIP")) c.sem.dbg_skip = (uint32_t)atoi(dbg);
 #endif
     c.serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(c.sem);
+    c.no_fused = (params->flags & S2K_FLAG_NO_FUSED) != 0;
     // The tiled kernel stages tiles with 16 B vector loads, i.e. it needs a 16 B aligned base pointer.  A misaligned
     // stream is first copied to an aligned buffer (one device-to-device pass, ~3 ms per 10 GB) instead of being handed to
     // the read-serial kernels as in round 1 (20-40x slower for the whole call).

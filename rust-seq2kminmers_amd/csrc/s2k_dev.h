@@ -105,24 +105,31 @@ struct Records { // SoA pool of minimizer records written by the minimizer kerne
 };
 
 // ---- fused single-pass emission: the tile kernel writes the final k-min-mers itself (s2k_tile_impl.h, FUSED = true) -------------
-// Output offsets need a prefix sum over the tiles; it is carried from tile to tile inside the kernel (decoupled look-back over
-// one descriptor per tile, every word self-validating: a 64-bit agent-scope store / load each, no fences).  What travels along
-// the tiles is the pair (G, p): G = k-min-mers (and, beside it, minimizers) before the tile, p = min(k-1, minimizers the read
-// that continues into the tile has so far).  A tile's own contribution is a small function of p -- see agg_* below.
+// Output offsets need a prefix sum over the tiles.  It is carried from tile to tile INSIDE the kernel, through descriptors in
+// global memory whose 64-bit words validate themselves (bit 63; one agent-scope store / load each, no fences):
+//  * word a of a tile, published as soon as its minimizers are counted: what the tile does to p = min(k-1, minimizers the read
+//    that continues across a tile boundary has so far) -- p after the tile = pass ? min(k-1, p + m_f) : q.  A tile finds its own
+//    p by looking back over the a words (a short chain: it ends at the first tile that holds a read start or k-1 minimizers);
+//  * word b, published once p is known: W = k-min-mers that END in the tile, N = its minimizers.  These add up, so the prefix
+//    is two-level: tiles form groups of 64; the last tile of a group (its "closer") publishes the group's sums (gb) and then
+//    the inclusive totals up to the group (gp0 / gp1), found by a look-back over the groups; a tile's own offset is
+//    gp(group before) + the b words of the earlier tiles of its group -- one round of loads.
+// Every wait is for a tile with a SMALLER index, which some running wave holds (tiles are handed out in increasing order and
+// every wave walks its tiles in increasing order) or has finished: the smallest unfinished tile never waits.  All polls are
+// bounded all the same: a wave that gives up sets Counts::need_unfused and poisons what follows, and the host re-runs the
+// call through the two-kernel path.
 struct TileDesc {
-    unsigned long long agg;  // the tile alone: valid | poison | pass | dep | q | N | C | m_f
-    unsigned long long pre0; // everything up to and including the tile: valid | poison | p | G (k-min-mers)
-    unsigned long long pre1; // ... valid | G (minimizers)
+    unsigned long long a; // valid | poison | pass (bit 61) | q [14,20) | m_f [0,14)
+    unsigned long long b; // valid | poison | N [20,34) | W [0,20)
+};
+struct GroupDesc {
+    unsigned long long gb;  // valid | poison | sum N [28,56) | sum W [0,28)    over the group's 64 tiles
+    unsigned long long gp0; // valid | poison | k-min-mers up to and including the group [0,48)
+    unsigned long long gp1; // valid | minimizers up to and including the group [0,48)
     unsigned long long pad;
 };
-constexpr unsigned long long TD_VALID = 1ull << 63, TD_POISON = 1ull << 62;
-// agg word: m_f bits [0,14) = minimizers of the tile's first read segment, C [14,28) = k-min-mers ending in the tile that do not
-// depend on p, N [28,42) = minimizers of the tile, q [42,48), dep bit 48, pass bit 49:
-//   k-min-mers ending in the tile = C + (dep ? max(0, m_f - (k-1) + p) : 0);   p after the tile = pass ? min(k-1, p + m_f) : q
-__host__ __device__ inline unsigned long long agg_pack(uint32_t m_f, uint32_t C, uint32_t N, uint32_t q, bool dep, bool pass) {
-    return TD_VALID | (unsigned long long)m_f | ((unsigned long long)C << 14) | ((unsigned long long)N << 28) | ((unsigned long long)q << 42) |
-           ((unsigned long long)(dep ? 1 : 0) << 48) | ((unsigned long long)(pass ? 1 : 0) << 49);
-}
+constexpr unsigned long long TD_VALID = 1ull << 63, TD_POISON = 1ull << 62, TD_PASS = 1ull << 61;
+constexpr int TILE_GROUP = 64; // tiles per group = lanes of a wave
 // Per tile, for the fix-up kernel that emits the k-min-mers whose minimizers lie in more than one tile: a header and the
 // first / last k-1 minimizers of the tile's first / last read segment.
 struct EdgeHdr {
@@ -140,6 +147,7 @@ __host__ __device__ inline uint32_t edge_stride(uint32_t k) { return (uint32_t)s
 
 struct Fused { // arguments of the fused path (all device pointers)
     TileDesc *desc;      // n_tiles, zeroed before the launch
+    GroupDesc *gdesc;    // ceil(n_tiles / 64), zeroed before the launch
     uint8_t *edge;       // n_tiles x edge_stride(k)
     uint32_t k, pad_;
     unsigned long long km_capacity, mn_capacity;

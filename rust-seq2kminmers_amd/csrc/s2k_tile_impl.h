@@ -57,15 +57,24 @@
 namespace s2k {
 namespace {
 
-constexpr int TW = 12;                                 // waves per block = all the waves of a CU (three per SIMD): ONE block per CU shares the two seed
+#ifndef S2K_TW
+#define S2K_TW 12
+#endif
+constexpr int TW = S2K_TW;                                 // waves per block = all the waves of a CU (three per SIMD): ONE block per CU shares the two seed
                                                        // tables, which leaves every wave ~1 KB more LDS than three blocks of four did (fused emission needs it)
 constexpr int HS_OFF = 16;                             // data starts here; byte HS_OFF-1 absorbs "slot -1" stores
 constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window slack
 constexpr int CAPP = 16;                               // positions per capture piece
 constexpr int NPC = TILE_T / CAPP;                     // 9 capture pieces per lane
 constexpr int MAX_L_TILED = 64;
-constexpr int LISTCAP = 256;                           // hits handled per dense batch
-constexpr int JOBCAP = 32;                             // queued hash re-derivations per flush
+#ifndef S2K_LISTCAP
+#define S2K_LISTCAP 256
+#endif
+#ifndef S2K_JOBCAP
+#define S2K_JOBCAP 32
+#endif
+constexpr int LISTCAP = S2K_LISTCAP;                           // hits handled per dense batch
+constexpr int JOBCAP = S2K_JOBCAP;                             // queued hash re-derivations per flush
 constexpr int REG_LA = 1;
 constexpr int HPC_LA = 2;                              // seed look-ahead (positions) of the Hpc hash loop: 8 spills there
 constexpr int NBL = 32;                                // read starts of a tile kept in LDS (hb / rs16); tiles with more search the read table
@@ -82,28 +91,34 @@ struct HpcLds {
 };
 struct NoHpcLds {};
 
-template <bool HPC>
-struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
+struct FusedLds {
+    uint32_t hv[LISTCAP];    // fused emission: 32-bit hash of every hit of the batch (written by the listing lanes and the re-derivation)
+    int32_t segadj[NBL];     // per read segment s of the tile: (windows ending before the segment) - (hits before it) - (hits of the segment that end no window)
+    uint16_t segb[NBL];      // ... and the number of hits before the segment
+};
+struct NoFusedLds {};
+
+template <bool HPC, bool FUSED>
+struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type, std::conditional<FUSED, FusedLds, NoFusedLds>::type {
     uint8_t buf[BUF_BYTES];
     union {
         struct {
             uint16_t list[LISTCAP];   // validated hits of the current batch: tile-local hash position (bits 0-13), ascending; bit 15 = hash must be re-derived
             uint16_t jobx[JOBCAP];    // hits whose hash must be re-derived: tile-local position ...
-            uint16_t jobslot[JOBCAP]; // ... and index of the hit inside the batch
+            uint16_t jobslot[JOBCAP]; // ... and index of the hit among the tile's hits
         };
-        uint64_t ring[64 + KMAX_FUSED]; // fused emission, once the list is dead: mixed hashes of the round's 64 hits behind the k-1 before them
+        uint64_t ring[FUSED ? 64 + KMAX_FUSED : 1]; // fused emission, once the list is dead: mixed hashes of the round's 64 hits behind the k-1 before them
     };
-    uint32_t hv[LISTCAP];    // fused emission: 32-bit hash of every hit of the batch (written by the listing lanes and the re-derivation)
     int16_t hb[NBL];         // read starts inside the tile, as hash-space positions (ascending; 0 .. TILE_BASES)
     uint16_t rs16[NBL];      // rs16[i] = read_off[r0 + i] - t0 for the read starts inside the tile (i >= 1; read r0 starts at rs0, kept in a register)
-    int32_t segadj[NBL];     // fused emission, per read segment s of the tile: (windows ending before the segment) - (hits before it) - (hits of the segment that end no window)
-    uint16_t segb[NBL];      // ... and the number of hits before the segment
 };
 constexpr int TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c], l-1)};  OUT table at 2048: {rotl(h[c], l), rotr(rc[c], 1)}
-template <bool HPC>
-constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>); }
+template <bool HPC, bool FUSED>
+constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC, FUSED>); }
 // one block of TW = 12 waves per CU: it may use the whole 160 KiB (MI355X_MICROARCH.md: "a single workgroup may declare all 160 KiB")
-static_assert(block_lds_bytes<true>() <= 160 * 1024, "the block of a CU must fit its 160 KiB of LDS");
+#ifndef S2K_EXPERIMENT
+static_assert(block_lds_bytes<true, true>() <= 160 * 1024, "the block of a CU must fit its 160 KiB of LDS");
+#endif
 
 // inclusive scan over the 64 lanes with DPP row shifts / broadcasts (no LDS round trips)
 __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -588,101 +603,128 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused path: what a run of consecutive tiles does to the pair (G, p) -- see TileDesc in s2k_dev.h -- and the look-back
-// that finds a tile's own (G, p) from the descriptors of the tiles before it.
-//   k-min-mers ending in the run = C + (dep ? max(0, m_f - (k-1) + p) : 0);     p after the run = pass ? min(k-1, p + m_f) : q
+// Fused path: the look-backs over the tile / group descriptors (TileDesc, GroupDesc in s2k_dev.h).  Wave-uniform control
+// flow; lane i looks at one descriptor.  `polls` counts the rounds that found something missing; false = gave up.
 // ------------------------------------------------------------------------------------------------
-struct AggF {
-    uint64_t m_f, C, N;
-    uint32_t q;
-    bool dep, pass;
-};
-__device__ __forceinline__ AggF agg_unpack(uint64_t w) {
-    AggF a;
-    a.m_f = w & 0x3FFFu;
-    a.C = (w >> 14) & 0x3FFFu;
-    a.N = (w >> 28) & 0x3FFFu;
-    a.q = (uint32_t)(w >> 42) & 63u;
-    a.dep = ((w >> 48) & 1u) != 0;
-    a.pass = ((w >> 49) & 1u) != 0;
-    return a;
-}
-__device__ __forceinline__ uint64_t agg_windows(const AggF &a, uint32_t p, uint32_t K1) {
-    uint64_t v = a.C;
-    if (a.dep && a.m_f + p > K1) v += a.m_f + p - K1;
-    return v;
-}
-__device__ __forceinline__ uint32_t agg_p(const AggF &a, uint32_t p, uint32_t K1) {
-    if (!a.pass) return a.q;
-    const uint64_t v = a.m_f + p;
-    return v > K1 ? K1 : (uint32_t)v;
-}
-// the run A followed by the run B
-__device__ __forceinline__ AggF agg_then(const AggF &A, const AggF &B, uint32_t K1) {
-    AggF R;
-    R.N = A.N + B.N;
-    if (A.pass) { // A is one stretch of a read that began earlier and goes on: no k-min-mer count of its own yet (C == 0)
-        R.dep = true;
-        R.pass = B.pass;
-        R.m_f = B.dep ? A.m_f + B.m_f : A.m_f; // max(0, a - K1 + p) + max(0, b - K1 + min(K1, p + a)) == max(0, a + b - K1 + p)
-        R.C = B.C;
-        R.q = B.q;
-    } else { // after A, p is the constant A.q
-        R.dep = A.dep;
-        R.pass = false;
-        R.m_f = A.m_f;
-        R.C = A.C + agg_windows(B, A.q, K1);
-        R.q = agg_p(B, A.q, K1);
-    }
-    return R;
-}
+__device__ __forceinline__ uint64_t ld_desc(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_desc(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
 }
-struct LbState {
-    uint64_t G, Gmn; // k-min-mers / minimizers before the tile
-    uint32_t p;      // min(k-1, minimizers the read that continues into the tile has so far)
-    bool poison, ok; // poison: a tile before this one could not be handled; !ok: gave up waiting
-};
-// Lane i looks at tile hi - i; the nearest tile whose inclusive pair is known ends the walk, the tiles between it and t must
-// have published their own contribution.  A wave waits here only for tiles that other waves are working on right now (tiles
-// are dealt in increasing order and every wave walks its tiles in increasing order, so the smallest unfinished tile never
-// waits); the number of polls is bounded all the same -- a wave that gives up poisons its successors and the host re-runs
-// the call through the two-kernel path.
-__device__ __forceinline__ LbState lookback(const TileDesc *desc, uint64_t t, int lane, uint32_t K1, uint32_t &polls) {
-    AggF suffix{0, 0, 0, 0, true, true}; // tiles (hi, t): nothing yet (the identity)
+__device__ __forceinline__ bool lb_wait(uint32_t &polls) {
+    if (++polls > (uint32_t)LB_POLL_LIMIT) return false;
+    __builtin_amdgcn_s_sleep(8);
+    return true;
+}
+// p of tile t: min(k-1, minimizers the read that continues into t has in the tiles before it).  Walks back over the a words:
+// a tile that holds a read start (or starts / ends with one) fixes p to its q, a tile that is one stretch of the read adds
+// its minimizers; the walk ends at the first of the former, or as soon as k-1 are counted.
+__device__ __forceinline__ bool p_lookback(const TileDesc *desc, uint64_t t, int lane, uint32_t K1, uint32_t &polls, uint32_t &p_out, bool &poison) {
+    uint32_t carried = 0; // minimizers of the stretch tiles of the windows already walked
     int64_t hi = (int64_t)t - 1;
-    bool poison = false;
-    constexpr unsigned long long M48 = (1ull << 48) - 1ull;
     for (;;) {
         const int64_t idx = hi - lane;
-        unsigned long long a = TD_VALID | (3ull << 48), p0 = TD_VALID, p1 = TD_VALID; // before tile 0: G = 0, p = 0
-        if (idx >= 0) {
-            a = __hip_atomic_load(&desc[idx].agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            p0 = __hip_atomic_load(&desc[idx].pre0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            p1 = __hip_atomic_load(&desc[idx].pre1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long a = idx >= 0 ? ld_desc(&desc[idx].a) : TD_VALID; // before tile 0: a read start, q = 0
+        const bool valid = (a & TD_VALID) != 0, passt = (a & TD_PASS) != 0;
+        const uint32_t contrib = valid ? (passt ? (uint32_t)(a & 0x3FFFu) : (uint32_t)(a >> 14) & 63u) : 0u;
+        const uint32_t sc = wave_incl_scan(contrib, lane); // lanes 0 .. i: the stretch tiles' minimizers, then the q of the tile that ends the walk
+        const uint64_t inval = __ballot(!valid), stop = __ballot(valid && !passt), full = __ballot(valid && carried + sc >= K1);
+        const int first_inval = inval ? __builtin_ctzll(inval) : 64;
+        const int first_stop = stop ? __builtin_ctzll(stop) : 64, first_full = full ? __builtin_ctzll(full) : 64;
+        const int e = first_stop < first_full ? first_stop : first_full;
+        if (e < first_inval) { // everything up to the deciding tile is known
+            const uint32_t v = carried + bcast(sc, e);
+            p_out = v < K1 ? v : K1;
+            poison = poison || (__ballot((a & TD_POISON) != 0) & ((2ull << e) - 1ull)) != 0;
+            return true;
         }
-        const uint64_t pre_ok = __ballot((p0 & TD_VALID) != 0 && (p1 & TD_VALID) != 0);
-        const uint64_t agg_ok = __ballot((a & TD_VALID) != 0);
-        const int jp = pre_ok ? __builtin_ctzll(pre_ok) : 64;
-        const uint64_t need = jp >= 64 ? ~0ull : ((1ull << jp) - 1ull);
-        if ((agg_ok & need) != need) { // a tile in between has not got that far yet
-            if (++polls > (uint32_t)LB_POLL_LIMIT) return LbState{0, 0, 0, true, false};
-            __builtin_amdgcn_s_sleep(8);
+        if (first_inval < 64) { // a tile in between has not published yet
+            if (!lb_wait(polls)) return false;
             continue;
         }
-        poison = poison || (__ballot((a & TD_POISON) != 0) & need) != 0;
-        AggF w{0, 0, 0, 0, true, true};
-        for (int i = (jp < 64 ? jp : 64) - 1; i >= 0; i--) w = agg_then(w, agg_unpack(readlane64(a, i)), K1); // earlier tiles first
-        suffix = agg_then(w, suffix, K1);
+        carried += bcast(sc, 63); // 64 stretch tiles with fewer than k-1 minimizers in all (very sparse): further back
+        hi -= 64;
+    }
+}
+// The closer of group g (the group's last tile) knows its own (W, N); it adds the b words of the group's earlier tiles,
+// publishes the group sums, finds the totals before the group by a look-back over the groups and publishes the inclusive
+// totals.  Returns the totals BEFORE the group in Gx / Gmnx.
+__device__ __forceinline__ bool close_group(const TileDesc *desc, GroupDesc *gdesc, uint64_t t, int lane, uint32_t myW, uint32_t myN, bool mypoison,
+                                            uint32_t &polls, uint64_t &Gx, uint64_t &Gmnx, uint32_t &Wbefore, uint32_t &Nbefore, bool &poison) {
+    const uint64_t g = t / TILE_GROUP;
+    const int mine = (int)(t % TILE_GROUP); // tiles g*64 .. t-1 are lanes 0 .. mine-1
+    constexpr unsigned long long M48 = (1ull << 48) - 1ull;
+    unsigned long long bw;
+    for (;;) {
+        bw = lane < mine ? ld_desc(&desc[g * TILE_GROUP + lane].b) : TD_VALID;
+        if (__ballot((bw & TD_VALID) == 0) == 0) break;
+        if (!lb_wait(polls)) return false;
+    }
+    poison = poison || mypoison || __ballot((bw & TD_POISON) != 0) != 0;
+    const uint32_t wl = lane < mine ? (uint32_t)(bw & 0xFFFFFu) : 0u, nl = lane < mine ? (uint32_t)(bw >> 20) & 0x3FFFu : 0u;
+    Wbefore = bcast(wave_incl_scan(wl, lane), 63);
+    Nbefore = bcast(wave_incl_scan(nl, lane), 63);
+    const uint64_t gW = (uint64_t)Wbefore + myW, gN = (uint64_t)Nbefore + myN;
+    if (lane == 0) st_desc(&gdesc[g].gb, TD_VALID | (poison ? TD_POISON : 0ull) | gW | (gN << 28));
+    // look-back over the groups
+    uint64_t accW = 0, accN = 0;
+    int64_t hi = (int64_t)g - 1;
+    for (;;) {
+        const int64_t idx = hi - lane;
+        unsigned long long gb = TD_VALID, p0 = TD_VALID, p1 = TD_VALID; // before group 0: totals 0
+        if (idx >= 0) {
+            gb = ld_desc(&gdesc[idx].gb);
+            p0 = ld_desc(&gdesc[idx].gp0);
+            p1 = ld_desc(&gdesc[idx].gp1);
+        }
+        const uint64_t pre_ok = __ballot((p0 & TD_VALID) != 0 && (p1 & TD_VALID) != 0), gb_ok = __ballot((gb & TD_VALID) != 0);
+        const int jp = pre_ok ? __builtin_ctzll(pre_ok) : 64;
+        const uint64_t need = jp >= 64 ? ~0ull : ((1ull << jp) - 1ull);
+        if ((gb_ok & need) != need) {
+            if (!lb_wait(polls)) return false;
+            continue;
+        }
+        poison = poison || (__ballot((gb & TD_POISON) != 0) & need) != 0;
+        const bool in = lane < jp;
+        // (two 32-bit scans per quantity: a group's sums stay below 2^28, 64 of them below 2^34)
+        const uint32_t w_lo = in ? (uint32_t)(gb & 0xFFFFFFFu) : 0u, n_lo = in ? (uint32_t)(gb >> 28) & 0xFFFFFFFu : 0u;
+        accW += (uint64_t)bcast(wave_incl_scan(w_lo & 0xFFFFu, lane), 63) + ((uint64_t)bcast(wave_incl_scan(w_lo >> 16, lane), 63) << 16);
+        accN += (uint64_t)bcast(wave_incl_scan(n_lo & 0xFFFFu, lane), 63) + ((uint64_t)bcast(wave_incl_scan(n_lo >> 16, lane), 63) << 16);
         if (jp < 64) {
             const uint64_t q0 = readlane64(p0, jp), q1 = readlane64(p1, jp);
-            const uint32_t p = (uint32_t)(q0 >> 48) & 63u;
-            return LbState{(q0 & M48) + agg_windows(suffix, p, K1), (q1 & M48) + suffix.N, agg_p(suffix, p, K1),
-                           poison || (q0 & TD_POISON) != 0, true};
+            poison = poison || (q0 & TD_POISON) != 0;
+            Gx = (q0 & M48) + accW;
+            Gmnx = (q1 & M48) + accN;
+            break;
         }
         hi -= 64;
     }
+    if (lane == 0) {
+        st_desc(&gdesc[g].gp0, TD_VALID | (poison ? TD_POISON : 0ull) | (Gx + gW));
+        st_desc(&gdesc[g].gp1, TD_VALID | (Gmnx + gN));
+    }
+    return true;
+}
+// k-min-mers / minimizers before tile t: the inclusive totals of the group before t's, plus the b words of the earlier tiles
+// of t's own group.
+__device__ __forceinline__ bool g_lookback(const TileDesc *desc, const GroupDesc *gdesc, uint64_t t, int lane, uint32_t &polls, uint64_t &G,
+                                           uint64_t &Gmn, bool &poison) {
+    const uint64_t g = t / TILE_GROUP;
+    const int mine = (int)(t % TILE_GROUP);
+    constexpr unsigned long long M48 = (1ull << 48) - 1ull;
+    unsigned long long bw, p0, p1;
+    for (;;) {
+        bw = lane < mine ? ld_desc(&desc[g * TILE_GROUP + lane].b) : TD_VALID;
+        p0 = g ? ld_desc(&gdesc[g - 1].gp0) : TD_VALID;
+        p1 = g ? ld_desc(&gdesc[g - 1].gp1) : TD_VALID;
+        if (__ballot((bw & TD_VALID) == 0 || (p0 & TD_VALID) == 0 || (p1 & TD_VALID) == 0) == 0) break;
+        if (!lb_wait(polls)) return false;
+    }
+    poison = poison || __ballot(((bw | p0) & TD_POISON) != 0) != 0;
+    const uint32_t wl = lane < mine ? (uint32_t)(bw & 0xFFFFFu) : 0u, nl = lane < mine ? (uint32_t)(bw >> 20) & 0x3FFFu : 0u;
+    G = (readlane64(p0, 0) & M48) + bcast(wave_incl_scan(wl, lane), 63);
+    Gmn = (readlane64(p1, 0) & M48) + bcast(wave_incl_scan(nl, lane), 63);
+    return true;
 }
 
 // Dense phase of one tile: hit bitmasks -> validated, ordered minimizers.
@@ -907,20 +949,32 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
         if constexpr (!FUSED)
             if ((uint32_t)lane <= nb && mine) atomicAdd(&mn_cnt[r0 + lane], mine);
     }
-    // ---- fused: the tile's own contribution to (G, p), published before anything else is done with the hits ---------------
+    // ---- fused: what the tile does to p, published before anything else is done with the hits -----------------------------
     const uint32_t K1 = FUSED ? fz.k - 1u : 0u;
     const bool dep = !(t0 == 0 || rs0 == t0); // a read that began before the tile continues into it
     uint32_t m_first = 0, m_last = 0, Cfix = 0, q_out = 0, n_head = 0, n_tail = 0;
     bool pass = false;
     uint8_t *const edge = FUSED ? fz.edge + t * (uint64_t)edge_stride(fz.k) : nullptr;
-    if constexpr (FUSED) {
-        if (many) { // reads shorter than ~300 bases: this tile is not handled here -- poison what follows, the host re-runs unfused
-            if (lane == 0) {
-                counts->need_unfused = 1;
-                __hip_atomic_store(&fz.desc[t].agg, TD_VALID | TD_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&fz.desc[t].pre0, TD_VALID | TD_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&fz.desc[t].pre1, TD_VALID | TD_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool closer = FUSED && ((t + 1) % TILE_GROUP == 0 || t + 1 == n_tiles); // the last tile of its group of 64
+    uint64_t G = 0, Gmn = 0;
+    uint32_t p_in = 0, Wt = 0;
+    bool poisoned = false, have_g = false;
+    auto give_up = [&]() { // a poll ran out (or this tile cannot be handled): poison what follows, the host re-runs unfused
+        poisoned = true;
+        if (lane == 0) {
+            counts->need_unfused = 1;
+            st_desc(&fz.desc[t].a, TD_VALID | TD_POISON);
+            st_desc(&fz.desc[t].b, TD_VALID | TD_POISON);
+            if (closer) {
+                st_desc(&fz.gdesc[t / TILE_GROUP].gb, TD_VALID | TD_POISON);
+                st_desc(&fz.gdesc[t / TILE_GROUP].gp0, TD_VALID | TD_POISON);
+                st_desc(&fz.gdesc[t / TILE_GROUP].gp1, TD_VALID | TD_POISON);
             }
+        }
+    };
+    if constexpr (FUSED) {
+        if (many) { // reads shorter than ~300 bases: more read starts than the LDS lists hold -- not handled by this path
+            give_up();
             issue_next(0u, base);
             return 0;
         }
@@ -933,31 +987,39 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
         q_out = ext_at_end ? 0u : (m_last < K1 ? m_last : K1);
         n_head = dep ? (m_first < K1 ? m_first : K1) : 0u;
         n_tail = ext_at_end ? 0u : (m_last < K1 ? m_last : K1);
-        if (lane == 0)
-            __hip_atomic_store(&fz.desc[t].agg, agg_pack(m_first, Cfix, N, q_out, dep, pass), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) st_desc(&fz.desc[t].a, TD_VALID | (pass ? TD_PASS : 0ull) | ((unsigned long long)q_out << 14) | m_first);
     }
-    // fused: (G, p) of this tile from the look-back, then everything that follows from it: the tile's inclusive pair for its
-    // successors, the edge header, per-segment output offsets, km_off of the reads that start here
-    uint64_t G = 0, Gmn = 0;
-    bool poisoned = false;
+    // fused, step 2 (after the hashes of the hits are settled): p of this tile from the a words before it, hence W = k-min-mers
+    // ending in the tile; publish b; the closer of a group also publishes the group's sums and totals
+    auto publish_b = [&]() {
+        if (dep) {
+            if (!p_lookback(fz.desc, t, lane, K1, lb_polls, p_in, poisoned)) return give_up();
+        }
+        Wt = Cfix + (dep && m_first + p_in > K1 ? m_first + p_in - K1 : 0u);
+        if (lane == 0) st_desc(&fz.desc[t].b, TD_VALID | (poisoned ? TD_POISON : 0ull) | Wt | ((unsigned long long)N << 20));
+        if (closer) {
+            uint64_t Gx = 0, Gmnx = 0;
+            uint32_t wb = 0, nbf = 0;
+            if (!close_group(fz.desc, fz.gdesc, t, lane, Wt, N, poisoned, lb_polls, Gx, Gmnx, wb, nbf, poisoned)) return give_up();
+            G = Gx + wb;
+            Gmn = Gmnx + nbf;
+            have_g = true;
+        }
+    };
+    // fused, step 4 (as late as possible): G of this tile, then everything that follows from it: the edge header, per-segment
+    // output offsets, km_off of the reads that start here
     auto resolve = [&]() {
-        const LbState lb = lookback(fz.desc, t, lane, K1, lb_polls);
+        if (!poisoned && !have_g) {
+            if (!g_lookback(fz.desc, fz.gdesc, t, lane, lb_polls, G, Gmn, poisoned)) give_up();
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70); // every vector-memory operation so far, the next tile's LDS-DMA loads included, is done
         dma_waited = true;
-        poisoned = lb.poison || !lb.ok;
-        if (!lb.ok && lane == 0) counts->need_unfused = 1;
-        const uint32_t p_in = dep ? lb.p : 0u;
-        G = lb.G;
-        Gmn = lb.Gmn;
+        if (poisoned && lane == 0) counts->need_unfused = 1;
         const uint32_t skip = lane == 0 ? (dep ? K1 - p_in : K1) : K1; // minimizers of a segment that end no k-min-mer
         const uint32_t wseg = (uint32_t)lane <= nb && mine > skip ? mine - skip : 0u;
         const uint32_t winc = wave_incl_scan(wseg, lane);
-        const uint32_t Wb = winc - wseg, Wt = bcast(winc, 63);
-        const uint32_t p_out = pass ? (p_in + m_first < K1 ? p_in + m_first : K1) : q_out;
+        const uint32_t Wb = winc - wseg; // (bcast(winc, 63) == Wt)
         if (lane == 0) {
-            const unsigned long long pz = poisoned ? TD_POISON : 0ull;
-            __hip_atomic_store(&fz.desc[t].pre0, TD_VALID | pz | ((unsigned long long)p_out << 48) | (G + Wt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&fz.desc[t].pre1, TD_VALID | pz | (Gmn + N), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             EdgeHdr h;
             h.g_excl = G;
             h.p_in = p_in;
@@ -967,9 +1029,11 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             h.pad = 0;
             *reinterpret_cast<EdgeHdr *>(edge) = h;
         }
-        if ((uint32_t)lane <= nb) {
-            S.segadj[lane] = (int32_t)Wb - (int32_t)segstart - (int32_t)skip;
-            S.segb[lane] = (uint16_t)segstart;
+        if constexpr (FUSED) { // (the lambda is instantiated for both paths; only the fused LDS layout has these)
+            if ((uint32_t)lane <= nb) {
+                S.segadj[lane] = (int32_t)Wb - (int32_t)segstart - (int32_t)skip;
+                S.segb[lane] = (uint16_t)segstart;
+            }
         }
         if (!poisoned) {
             const uint32_t nrd = r1 - r0; // reads r0+1 .. r1 start in (t0, end of the tile]: the first nb inside, the rest exactly at the end
@@ -994,6 +1058,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     if constexpr (FUSED) {
         if (N == 0) {
             issue_next(0u, base);
+            publish_b();
             resolve();
             if (lane == 0 && lb_polls) atomicAdd(&counts->lb_polls[t & 63], lb_polls);
             return 0;
@@ -1127,6 +1192,8 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
         if (njobs) flush_jobs(b0);
         S2K_STAMP(12); // hash re-derivation
         if (b0 + (uint32_t)LISTCAP >= N) issue_next(N, base);
+        if constexpr (FUSED)
+            if (b0 == 0) publish_b();
         // one hit per lane: tile-local hash position -> stream positions of the l-mer's first base and of the last base that belongs
         // to it, and the read it lies in (number of read starts at or before it, among those kept in LDS)
         auto backmap = [&](uint32_t x, uint64_t &p, uint64_t &e1) {
@@ -1320,7 +1387,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
     uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts, const Fused *fzp) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    using WL = WaveLdsT<HPC>;
+    using WL = WaveLdsT<HPC, FUSED>;
     uint2 *tab = reinterpret_cast<uint2 *>(smem);
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap(); // lut() assumes it
     const int lane0 = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: everything per tile is scalar
@@ -1656,7 +1723,7 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
                            uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
                            uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts, const Fused *d_fz) {
     auto kern = tile_minimizer_kernel<L, HPC, FUSED>;
-    const int lds = block_lds_bytes<HPC>();
+    const int lds = block_lds_bytes<HPC, FUSED>();
     // per instantiation AND per device: function attributes and occupancy belong to the device the module is loaded on
     // (contexts on different threads may launch concurrently: the cache is filled under a lock)
     constexpr int MAX_DEV = 64;
