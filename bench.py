@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: map every rank to GPU 0")
     ap.add_argument("--count", action="store_true", help="also time the downstream k-min-mer count (hash table in HBM; N > 1: all-to-all by hash prefix)")
-    ap.add_argument("--no-fused", action="store_true", help="two-kernel path (tile kernel + k-min-mer kernel) instead of the fused single pass")
+    ap.add_argument("--legacy-path", action="store_true", help="legacy records (16 B with the read index + per-read scans) instead of the descriptor path")
     ap.add_argument("--dump-shard", default=None, help="(tests) write this rank's outputs to <path>.rank<r>.npz")
     return ap.parse_args()
 
@@ -207,7 +207,7 @@ def main():
 
     def step(m, sync=False):
         return eng.extract_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases, args.l, args.k, args.density, m, o, sync=sync,
-                                  flags=pkg.FLAG_NO_FUSED if args.no_fused else 0)
+                                  flags=pkg.FLAG_LEGACY_PATH if args.legacy_path else 0)
 
     def barrier():
         if dist is not None:
@@ -238,7 +238,7 @@ def main():
         return dt, counts, k_ms / steps, km_ms / steps, all_ms / steps
 
     dt, counts, min_ms, km_ms, pipe_ms = timed(mode, args.steps, args.warmup)
-    assert counts["path"] == (2 if args.no_fused else 0), "the tiled HIP kernels (fused single pass unless --no-fused) must be the ones measured"
+    assert counts["path"] == (2 if args.legacy_path else 0), "the tiled HIP kernels (descriptor path unless --legacy-path) must be the ones measured"
     # ---- verification outside the timed region: a read sample against the oracle ------------------
     verified = None
     if rank == 0 and args.verify_reads > 0:

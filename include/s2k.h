@@ -64,7 +64,7 @@ enum {
     S2K_FLAG_WANT_MINIMIZERS = 1u << 0, /* also return the (j, jend, hash32) triples (NtHashHPCIterator::Item, src/nthash_hpc.rs:193) */
     S2K_FLAG_FORCE_SERIAL = 1u << 1,    /* use the read-serial kernels (exact for every input; slow) instead of the tiled ones */
     S2K_FLAG_NO_PACK2 = 1u << 2,        /* s2k_extract, s2k_run_file: send the text as it is instead of 2-bit packed (+ exception list) over PCIe */
-    S2K_FLAG_NO_FUSED = 1u << 3         /* tiled kernel + separate k-min-mer kernel (counts.path 2) instead of the single pass that writes the k-min-mers itself */
+    S2K_FLAG_LEGACY_PATH = 1u << 3      /* tiled kernels with the round-2 records (16 B with the read index, per-read scans; counts.path 2) instead of the descriptor path */
 };
 
 typedef struct s2k_params {
@@ -82,8 +82,8 @@ typedef struct s2k_counts {
     uint64_t n_kminmers;
     uint64_t xor_hash;   /* XOR of all k-min-mer hashes (cheap whole-run checksum) */
     uint32_t hash_bound; /* the u32 bound of src/lib.rs:91 that was used */
-    uint32_t path;       /* 0 = tiled kernel, single pass (it writes the k-min-mers itself); 1 = read-serial kernels;
-                          * 2 = tiled kernel + k-min-mer kernel (k > 32, or a tile with more than 30 read starts) */
+    uint32_t path;       /* 0 = tiled kernels, descriptor path (8-byte tile-relative records); 1 = read-serial kernels;
+                          * 2 = tiled kernels, legacy records (k > 32, a tile with more than 30 read starts, S2K_FLAG_LEGACY_PATH) */
 } s2k_counts;
 
 /* Host-side result, SoA.  Item i of read r (km_off[r] <= i < km_off[r+1]) is

@@ -39,7 +39,7 @@ class HashMode(enum.IntEnum):  # src/lib.rs:21-27
 
 FLAG_WANT_MINIMIZERS = 1
 FLAG_FORCE_SERIAL = 2
-FLAG_NO_FUSED = 8  # tiled kernel + separate k-min-mer kernel instead of the fused single pass
+FLAG_LEGACY_PATH = 8  # round-2 records (16 B with the read index, per-read scans) instead of the descriptor path
 FLAG_NO_PACK2 = 4  # s2k_extract: bases as ASCII over PCIe instead of 2-bit packed + exception list
 HPC_RLE_ALPHABET = 1  # s2k_hpc_device_ex: the run rule of encode_rle (src/hpc.rs:14)
 
@@ -218,7 +218,7 @@ class Engine:
         return float(ms.value), int(n.value)
 
     # ---- host-buffer API (s2k_extract) ---------------------------------------------------------------
-    def extract(self, bases, read_off, l, k, density, mode=HashMode.Hpc, want_minimizers=False, force_serial=False, pack2=True, fused=True):
+    def extract(self, bases, read_off, l, k, density, mode=HashMode.Hpc, want_minimizers=False, force_serial=False, pack2=True, legacy=False):
         """Batch counterpart of `for r in reads: KminmersIterator::new(r,l,k,d,mode).collect()`.
         Returns a dict of numpy arrays (copies)."""
         bases = _as_u8(bases)
@@ -228,7 +228,7 @@ class Engine:
         if int(read_off[-1]) > len(bases):
             raise ValueError("read_off[-1] = %d lies past the end of bases (%d bytes)" % (int(read_off[-1]), len(bases)))
         n_reads = len(read_off) - 1  # read_off[0] may be > 0: the library rebases the offsets (bases[read_off[0]:read_off[-1]] is used)
-        flags = (FLAG_WANT_MINIMIZERS if want_minimizers else 0) | (FLAG_FORCE_SERIAL if force_serial else 0) | (0 if pack2 else FLAG_NO_PACK2) | (0 if fused else FLAG_NO_FUSED)
+        flags = (FLAG_WANT_MINIMIZERS if want_minimizers else 0) | (FLAG_FORCE_SERIAL if force_serial else 0) | (0 if pack2 else FLAG_NO_PACK2) | (FLAG_LEGACY_PATH if legacy else 0)
         p = Params(int(l), int(k), float(density), int(mode), flags)
         res = Result()
         self._check(self.lib.s2k_extract(self.ctx, bases.ctypes.data_as(C.c_void_p), read_off.ctypes.data_as(C.c_void_p),

@@ -155,8 +155,8 @@ struct Call { // everything needed to (re-)enqueue one extraction
     Sem sem{};
     uint32_t bound = 0;
     bool serial = false;
-    bool fused_run = false; // what the last enqueue() took
-    bool no_fused = false; // the fused single-pass path met something it does not handle: the re-run takes the two-kernel path
+    bool desc_run = false; // what the last enqueue() took
+    bool legacy = false;   // S2K_FLAG_LEGACY_PATH, or the descriptor path met something it does not handle: the (re-)run takes the legacy records
     uint64_t pool_cap = 0; // serial: dense record capacity; tiled: capacity of the overflow region
     uint64_t slab_cap = 0; // tiled: records per tile slab
     bool valid = false;
@@ -317,15 +317,14 @@ s2k_status enqueue(s2k_ctx *ctx) {
     uint32_t *mn_cnt = nullptr, *tile_read0 = nullptr, *tile_cnt = nullptr;
     uint64_t *mn_off = nullptr, *tile_rec_off = nullptr, *tile_goff = nullptr, *scan_tmp = nullptr, *pool_cursor = nullptr;
     const bool want_runs = !c.serial && c.sem.hpc && c.sem.tail_quirk; // HpcSimd on the tiled kernel
-    // fused single-pass path: the tiled kernel writes the final k-min-mers itself (no record pool, no scans, no second kernel)
-    const bool fused = !c.serial && !c.no_fused && n_tiles >= 1 && n_reads >= 1 && c.sem.k <= 32;
-    c.fused_run = fused;
-    TileDesc *desc = nullptr;
-    GroupDesc *gdesc = nullptr;
-    const uint64_t n_groups = (n_tiles + TILE_GROUP - 1) / TILE_GROUP;
-    uint8_t *edge = nullptr;
-    uint64_t *totals = nullptr;
-    Fused *d_fz = nullptr;
+    // descriptor path (default): 8-byte tile-relative records + one word and a segment list per tile, a scan over the tile words,
+    // and a k-min-mer kernel that needs no per-read table (s2k_desc.hip).  Legacy path: 16-byte records with the read index,
+    // per-read counters and three scans (k > 32, tiles with more than 30 read starts, S2K_FLAG_LEGACY_PATH).
+    const bool use_desc = !c.serial && !c.legacy && n_tiles >= 1 && n_reads >= 1 && c.sem.k <= 32;
+    c.desc_run = use_desc;
+    unsigned long long *d_agg = nullptr, *d_scan = nullptr;
+    TileMeta *d_meta = nullptr;
+    TileState *d_state = nullptr;
     const uint64_t n_runblk = n_bases / 256 + 1;
     uint32_t *run_blk = nullptr, *read_runs = nullptr;
     uint64_t *run_off = nullptr, *run_tmp = nullptr;
@@ -348,18 +347,17 @@ s2k_status enqueue(s2k_ctx *ctx) {
             run_tmp = a.take<uint64_t>(scan_tmp_bytes(n_runblk) / sizeof(uint64_t) + 1);
             read_runs = a.take<uint32_t>(n_reads + 1);
         }
-        if (fused) {
-            desc = a.take<TileDesc>(n_tiles);
-            gdesc = a.take<GroupDesc>(n_groups);
-            edge = a.take<uint8_t>(n_tiles * (uint64_t)edge_stride(c.sem.k));
-            totals = a.take<uint64_t>(2);
-            d_fz = a.take<Fused>(1);
+        if (use_desc) {
+            d_agg = a.take<unsigned long long>(n_tiles);
+            d_meta = a.take<TileMeta>(n_tiles);
+            d_state = a.take<TileState>(n_tiles + 1);
+            d_scan = a.take<unsigned long long>(desc_scan_tmp_words(n_tiles));
         }
-        const uint64_t rec_total = fused ? 0 : (c.serial ? c.pool_cap : n_tiles * c.slab_cap + c.pool_cap);
+        const uint64_t rec_total = c.serial ? c.pool_cap : n_tiles * c.slab_cap + c.pool_cap;
         rec.j = a.take<uint32_t>(rec_total);
-        rec.jend = a.take<uint32_t>(rec_total);
         rec.hash = a.take<uint32_t>(rec_total);
-        rec.rid = a.take<uint32_t>(rec_total);
+        rec.jend = use_desc ? nullptr : a.take<uint32_t>(rec_total); // (descriptor path: rec.j holds {offset in the tile, span})
+        rec.rid = use_desc ? nullptr : a.take<uint32_t>(rec_total);
         rec.capacity = rec_total;
         rec.slab_cap = c.serial ? 0 : c.slab_cap;
         rec.ovf_base = c.serial ? 0 : n_tiles * c.slab_cap;
@@ -411,36 +409,38 @@ s2k_status enqueue(s2k_ctx *ctx) {
                     "run count kernels");
             sem.read_runs = read_runs;
         }
-        if (fused) {
-            Fused fz{};
-            fz.desc = desc;
-            fz.gdesc = gdesc;
-            fz.edge = edge;
-            fz.k = c.sem.k;
-            fz.km_capacity = o.km_capacity;
-            fz.mn_capacity = o.mn_capacity;
-            fz.o_km_off = (unsigned long long *)o.km_off;
-            fz.o_hash = (unsigned long long *)o.hash;
-            fz.o_start = o.start;
-            fz.o_end = o.end;
-            fz.o_rev = o.rev;
-            fz.o_mn_off = (unsigned long long *)mn_off; // the caller's, or workspace
-            fz.o_mn_j = o.mn_j;
-            fz.o_mn_jend = o.mn_jend;
-            fz.o_mn_hash = o.mn_hash;
-            fz.xor_shards = (unsigned long long *)ctx->d_xor;
-            fz.totals = (unsigned long long *)totals;
-            S2K_TRY(hipMemsetAsync(desc, 0, n_tiles * sizeof(TileDesc), st), "memset tile descriptors");
-            S2K_TRY(hipMemsetAsync(gdesc, 0, n_groups * sizeof(GroupDesc), st), "memset group descriptors");
+        if (use_desc) {
+            Desc dz{};
+            dz.agg = d_agg;
+            dz.meta = d_meta;
+            dz.state = d_state;
+            dz.k = c.sem.k;
+            dz.km_capacity = o.km_capacity;
+            dz.mn_capacity = o.mn_capacity;
+            dz.o_km_off = (unsigned long long *)o.km_off;
+            dz.o_hash = (unsigned long long *)o.hash;
+            dz.o_start = o.start;
+            dz.o_end = o.end;
+            dz.o_rev = o.rev;
+            dz.o_mn_off = (unsigned long long *)mn_off; // the caller's, or workspace
+            dz.o_mn_j = o.mn_j;
+            dz.o_mn_jend = o.mn_jend;
+            dz.o_mn_hash = o.mn_hash;
+            dz.xor_shards = (unsigned long long *)ctx->d_xor;
+            // (a tile without a single hash position -- Simd modes with bound 0 -- writes no word: zero = "nothing, passes p on")
+            S2K_TRY(hipMemsetAsync(d_agg, 0, n_tiles * sizeof(unsigned long long), st), "memset tile words");
             if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
             S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, nullptr,
-                                           nullptr, nullptr, ctx->d_counts, &fz, d_fz, st),
-                    "tiled minimizer kernel (fused)");
+                                           nullptr, nullptr, ctx->d_counts, &dz, st),
+                    "tiled minimizer kernel");
             if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
+            S2K_TRY(launch_desc_scan(n_tiles, dz, d_scan, ctx->d_counts, st), "tile word scan");
             if (tm) S2K_TRY(hipEventRecord(ctx->ev[3], st), "event");
-            S2K_TRY(launch_fused_fixup(n_tiles, fz, ctx->d_counts, st), "fix-up kernel");
+            S2K_TRY(launch_desc_kminmers(n_tiles, n_reads, dz, rec, ctx->d_counts, st), "k-min-mer kernel");
             if (tm) S2K_TRY(hipEventRecord(ctx->ev[4], st), "event");
-            S2K_TRY(launch_finalize(ctx->d_counts, ctx->d_xor, totals, totals + 1, o.km_capacity, o.mn_capacity, st), "finalize kernel");
+            S2K_TRY(launch_finalize(ctx->d_counts, ctx->d_xor, (const uint64_t *)&d_state[n_tiles].gmn, (const uint64_t *)&d_state[n_tiles].g,
+                                    o.km_capacity, o.mn_capacity, st),
+                    "finalize kernel");
             S2K_TRY(hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(Counts), hipMemcpyDeviceToHost, st), "counts copy");
             if (tm) S2K_TRY(hipEventRecord(ctx->ev[5], st), "event");
             ctx->pending = true;
@@ -448,7 +448,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
         }
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
         S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
-                                       tile_rec_off, tile_cnt, mn_cnt, ctx->d_counts, nullptr, nullptr, st),
+                                       tile_rec_off, tile_cnt, mn_cnt, ctx->d_counts, nullptr, st),
                 "tiled minimizer kernel");
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
         S2K_TRY(launch_scan_u32(tile_cnt, n_tiles, tile_goff, scan_tmp, 0, st), "scan");
@@ -488,9 +488,9 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
             c.valid = false;
             return ctx->pending_status;
         }
-        if (h->need_unfused) { // the fused path met a tile with more read starts than it keeps in LDS (reads shorter than ~300
-                               // bases), or a look-back gave up: the whole call takes the two-kernel path
-            c.no_fused = true;
+        if (h->need_legacy && c.desc_run) { // the descriptor path met a tile with more read starts than it lists (reads shorter than
+                                            // ~300 bases) or a span that does not fit its records: the whole call takes the legacy path
+            c.legacy = true;
             s2k_status st = enqueue(ctx);
             if (st != S2K_OK) return st;
             continue;
@@ -504,7 +504,7 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
         h->n_reads = c.n_reads;
         h->n_bases = c.n_bases;
         h->hash_bound = c.bound;
-        h->path = c.serial ? 1u : (c.fused_run ? 0u : 2u);
+        h->path = c.serial ? 1u : (c.desc_run ? 0u : 2u);
         if (c.sem.dbg_skip & 32) // KNOBS builds: spread of the waves' finishing times in the tiled kernel
         {
             fprintf(stderr, "[s2k dbg] last wave finished %.1f us after the first\n", (double)(h->dbg_cycles[0][0] - ~h->dbg_cycles[0][1]) * 0.01);
@@ -526,15 +526,6 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
                 fprintf(stderr, " %llu", sum);
             }
             fprintf(stderr, "\n");
-        }
-        {
-            static const bool dbg_lb = getenv("S2K_DEBUG_LB") != nullptr; // diagnostics of the fused path's look-back (stderr)
-            if (dbg_lb && c.fused_run) {
-                unsigned long long polls = 0;
-                for (int i = 0; i < 64; i++) polls += h->lb_polls[i];
-                const uint64_t nt = (c.n_bases + TILE_BASES - 1) / TILE_BASES;
-                fprintf(stderr, "[s2k lb] tiles %llu look-back polls %llu (%.2f per tile)\n", (unsigned long long)nt, polls, nt ? (double)polls / (double)nt : 0.0);
-            }
         }
         if (counts) memcpy(counts, h, sizeof(s2k_counts));
         ctx->pending_status = (h->km_overflow || h->mn_overflow) ? S2K_ERR_CAPACITY : S2K_OK;
@@ -713,7 +704,7 @@ s2k_status s2k_extract_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64
     if (const char *dbg = getenv("S2K_DEBUG_SKIP")) c.sem.dbg_skip = (uint32_t)atoi(dbg);
 #endif
     c.serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(c.sem);
-    c.no_fused = (params->flags & S2K_FLAG_NO_FUSED) != 0;
+    c.legacy = (params->flags & S2K_FLAG_LEGACY_PATH) != 0;
     // The tiled kernel stages tiles with 16 B vector loads, i.e. it needs a 16 B aligned base pointer.  A misaligned
     // stream is first copied to an aligned buffer (one device-to-device pass, ~3 ms per 10 GB) instead of being handed to
     // the read-serial kernels as in round 1 (20-40x slower for the whole call).

@@ -62,8 +62,7 @@ struct Counts { // mirrored by s2k_counts (include/s2k.h)
     // internal
     uint64_t pool_needed;
     uint32_t pool_overflow, bad_input, km_overflow, mn_overflow; // bad_input: BAD_* bits set by validate_read_off_kernel
-    uint32_t need_unfused, pad2_;
-    uint32_t lb_polls[64]; // look-back polls of the fused path (diagnostics), sharded
+    uint32_t need_legacy, pad2_; // descriptor path: a tile it cannot handle was met (> 30 read starts, a span >= 2^18): the host re-runs the call through the legacy path
     // fused path: a tile it cannot handle was met (or a look-back timed out): the host re-runs the call unfused
     uint64_t dbg_cycles[64][16]; // S2K_DEBUG_SKIP & 8: shader-clock cycles per phase, summed over waves
 #ifdef S2K_DEBUG_KNOBS
@@ -104,51 +103,86 @@ struct Records { // SoA pool of minimizer records written by the minimizer kerne
     uint64_t slab_cap, ovf_base;
 };
 
-// ---- fused single-pass emission: the tile kernel writes the final k-min-mers itself (s2k_tile_impl.h, FUSED = true) -------------
-// Output offsets need a prefix sum over the tiles.  It is carried from tile to tile INSIDE the kernel, through descriptors in
-// global memory whose 64-bit words validate themselves (bit 63; one agent-scope store / load each, no fences):
-//  * word a of a tile, published as soon as its minimizers are counted: what the tile does to p = min(k-1, minimizers the read
-//    that continues across a tile boundary has so far) -- p after the tile = pass ? min(k-1, p + m_f) : q.  A tile finds its own
-//    p by looking back over the a words (a short chain: it ends at the first tile that holds a read start or k-1 minimizers);
-//  * word b, published once p is known: W = k-min-mers that END in the tile, N = its minimizers.  These add up, so the prefix
-//    is two-level: tiles form groups of 64; the last tile of a group (its "closer") publishes the group's sums (gb) and then
-//    the inclusive totals up to the group (gp0 / gp1), found by a look-back over the groups; a tile's own offset is
-//    gp(group before) + the b words of the earlier tiles of its group -- one round of loads.
-// Every wait is for a tile with a SMALLER index, which some running wave holds (tiles are handed out in increasing order and
-// every wave walks its tiles in increasing order) or has finished: the smallest unfinished tile never waits.  All polls are
-// bounded all the same: a wave that gives up sets Counts::need_unfused and poisons what follows, and the host re-runs the
-// call through the two-kernel path.
-struct TileDesc {
-    unsigned long long a; // valid | poison | pass (bit 61) | q [14,20) | m_f [0,14)
-    unsigned long long b; // valid | poison | N [20,34) | W [0,20)
+// ---- descriptor path (the default for k <= 32): tile-relative records + one descriptor word per tile -----------------------------
+// The tiled kernel leaves, per minimizer, 8 bytes -- its 32-bit hash and {offset of the l-mer's first base inside the tile : 14,
+// span to its last base : 18} -- and, per tile, one word that says what the tile does to the pair (G, p):
+//   G = k-min-mers that end before the tile (and, beside it, minimizers before the tile),
+//   p = min(k-1, minimizers the read that continues into the tile has so far),
+// namely   k-min-mers ending in the tile = C + (dep ? max(0, m_f - (k-1) + p) : 0),   p after the tile = pass ? min(k-1, p + m_f) : q.
+// These functions compose associatively (agg_then), so one small scan over the tile words (s2k_desc.hip) gives every tile its
+// (G, p); the k-min-mer kernel then needs no per-read table at all: a window that ends at the i-th minimizer of a tile goes to
+// G + (windows ending earlier in the tile), read positions come from the tile's own list of read starts.  (Round 2 kept 16-byte
+// records with the read index, three scans over per-read / per-tile counters and three dependent global round trips per tile
+// in the k-min-mer kernel; that path is still here for k > 32 and for tiles with more than 30 read starts.)
+struct AggF {
+    uint64_t m_f, C, N;
+    uint32_t q;
+    bool dep, pass;
 };
-struct GroupDesc {
-    unsigned long long gb;  // valid | poison | sum N [28,56) | sum W [0,28)    over the group's 64 tiles
-    unsigned long long gp0; // valid | poison | k-min-mers up to and including the group [0,48)
-    unsigned long long gp1; // valid | minimizers up to and including the group [0,48)
-    unsigned long long pad;
+// agg word: m_f bits [0,14) = minimizers of the tile's first read segment, C [14,28) = k-min-mers ending in the tile that do not
+// depend on p, N [28,42) = minimizers of the tile, q [42,48), dep bit 48, pass bit 49
+__host__ __device__ inline unsigned long long agg_pack(uint32_t m_f, uint32_t C, uint32_t N, uint32_t q, bool dep, bool pass) {
+    return (unsigned long long)m_f | ((unsigned long long)C << 14) | ((unsigned long long)N << 28) | ((unsigned long long)q << 42) |
+           ((unsigned long long)(dep ? 1 : 0) << 48) | ((unsigned long long)(pass ? 1 : 0) << 49);
+}
+__host__ __device__ inline AggF agg_unpack(unsigned long long w) {
+    AggF a;
+    a.m_f = w & 0x3FFFu;
+    a.C = (w >> 14) & 0x3FFFu;
+    a.N = (w >> 28) & 0x3FFFu;
+    a.q = (uint32_t)(w >> 42) & 63u;
+    a.dep = ((w >> 48) & 1u) != 0;
+    a.pass = ((w >> 49) & 1u) != 0;
+    return a;
+}
+__host__ __device__ inline AggF agg_identity() { return AggF{0, 0, 0, 0, true, true}; }
+__host__ __device__ inline uint64_t agg_windows(const AggF &a, uint32_t p, uint32_t K1) {
+    uint64_t v = a.C;
+    if (a.dep && a.m_f + p > K1) v += a.m_f + p - K1;
+    return v;
+}
+__host__ __device__ inline uint32_t agg_p(const AggF &a, uint32_t p, uint32_t K1) {
+    if (!a.pass) return a.q;
+    const uint64_t v = a.m_f + p;
+    return v > K1 ? K1 : (uint32_t)v;
+}
+// the run A followed by the run B
+__host__ __device__ inline AggF agg_then(const AggF &A, const AggF &B, uint32_t K1) {
+    AggF R;
+    R.N = A.N + B.N;
+    if (A.pass) { // A is one stretch of a read that began earlier and goes on: no k-min-mer count of its own yet (C == 0)
+        R.dep = true;
+        R.pass = B.pass;
+        R.m_f = B.dep ? A.m_f + B.m_f : A.m_f; // max(0, a - K1 + p) + max(0, b - K1 + min(K1, p + a)) == max(0, a + b - K1 + p)
+        R.C = B.C;
+        R.q = B.q;
+    } else { // after A, p is the constant A.q
+        R.dep = A.dep;
+        R.pass = false;
+        R.m_f = A.m_f;
+        R.C = A.C + agg_windows(B, A.q, K1);
+        R.q = agg_p(B, A.q, K1);
+    }
+    return R;
+}
+constexpr int META_SEGS = 32; // read segments of a tile whose start is kept (NBL of s2k_tile_impl.h); tiles with more take the legacy path
+struct TileMeta {            // written by the tiled kernel, read by the k-min-mer kernel
+    unsigned long long rec_base; // the tile's first record in the pool (its slab, or a piece of the overflow region)
+    unsigned long long rs0;      // stream position where read r0 (the one that holds the tile's first base) starts
+    uint32_t r0;                 // index of that read
+    uint16_t nb, nrd;            // read starts strictly inside the tile; reads that start in (t0, end of the tile]
+    uint16_t segstart[META_SEGS]; // minimizers of the tile before read segment s (s = 0 .. nb)
+    uint16_t rs16[META_SEGS];     // read_off[r0 + s] - t0 for s = 1 .. nb
 };
-constexpr unsigned long long TD_VALID = 1ull << 63, TD_POISON = 1ull << 62, TD_PASS = 1ull << 61;
-constexpr int TILE_GROUP = 64; // tiles per group = lanes of a wave
-// Per tile, for the fix-up kernel that emits the k-min-mers whose minimizers lie in more than one tile: a header and the
-// first / last k-1 minimizers of the tile's first / last read segment.
-struct EdgeHdr {
-    unsigned long long g_excl; // k-min-mers before the tile
-    uint32_t p_in;             // min(k-1, minimizers of the continuing read before the tile); 0 when the tile starts a read
-    uint32_t n_head;           // entries of head[]: min(k-1, minimizers of the first segment), 0 when no read continues into the tile
-    uint32_t n_tail;           // entries of tail[]: min(k-1, minimizers of the last segment)
-    uint32_t flags;            // bit 0: the tile is one segment of a read that began earlier (walk further back for more)
-    unsigned long long pad;
+struct TileState { // written by the scan
+    unsigned long long g;   // p << 48 | k-min-mers that end before the tile
+    unsigned long long gmn; // minimizers before the tile
 };
-struct EdgeRec {
-    uint32_t hash, pos; // head[]: pos = jend; tail[]: pos = j
-};
-__host__ __device__ inline uint32_t edge_stride(uint32_t k) { return (uint32_t)sizeof(EdgeHdr) + 2u * (k - 1u) * (uint32_t)sizeof(EdgeRec); }
-
-struct Fused { // arguments of the fused path (all device pointers)
-    TileDesc *desc;      // n_tiles, zeroed before the launch
-    GroupDesc *gdesc;    // ceil(n_tiles / 64), zeroed before the launch
-    uint8_t *edge;       // n_tiles x edge_stride(k)
+constexpr uint32_t REC_SPAN_MAX = (1u << 18) - 1u; // a span that does not fit sends the call to the legacy path
+struct Desc { // arguments of the descriptor path (device pointers)
+    unsigned long long *agg; // n_tiles
+    TileMeta *meta;          // n_tiles
+    TileState *state;        // n_tiles + 1 (the last entry holds the totals)
     uint32_t k, pad_;
     unsigned long long km_capacity, mn_capacity;
     unsigned long long *o_km_off, *o_hash;
@@ -157,7 +191,6 @@ struct Fused { // arguments of the fused path (all device pointers)
     unsigned long long *o_mn_off; // with mn_capacity != 0
     uint32_t *o_mn_j, *o_mn_jend, *o_mn_hash;
     unsigned long long *xor_shards;
-    unsigned long long *totals;   // [0] minimizers, [1] k-min-mers of the whole call (written by the last tile)
 };
 
 #define S2K_HIP_CHECK(expr)                                                      \
@@ -212,13 +245,16 @@ hipError_t launch_finalize(Counts *counts, const uint64_t *xor_shards, const uin
 
 hipError_t launch_tile_index(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles,
                              uint32_t *tile_read0, hipStream_t st);
-// fused != nullptr: single pass, final k-min-mers written by the kernel (rec / tile_rec_off / tile_cnt / mn_cnt unused)
+// desc != nullptr: descriptor path (8-byte records in rec.hash / rec.j, agg word + meta per tile; tile_rec_off / tile_cnt / mn_cnt unused)
 hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                   uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec,
                                   uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
-                                  Counts *counts, const Fused *fused, Fused *d_fused /* device scratch for *fused */, hipStream_t st);
-// the k-min-mers whose k minimizers lie in more than one tile (fused path), from the tiles' edge records
-hipError_t launch_fused_fixup(uint64_t n_tiles, Fused fz, const Counts *counts, hipStream_t st);
+                                  Counts *counts, const Desc *desc, hipStream_t st);
+// descriptor path: (G, p) of every tile from the tile words (state[n_tiles] = the totals), then the k-min-mers
+hipError_t launch_desc_scan(uint64_t n_tiles, Desc dz, unsigned long long *scan_tmp /* desc_scan_tmp_words(n_tiles) */, const Counts *counts,
+                            hipStream_t st);
+size_t desc_scan_tmp_words(uint64_t n_tiles);
+hipError_t launch_desc_kminmers(uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts, hipStream_t st);
 
 hipError_t launch_hpc_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint32_t *run_cnt, hipStream_t st,
                             bool rle = false);

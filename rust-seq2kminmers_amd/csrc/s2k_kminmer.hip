@@ -303,81 +303,7 @@ __global__ __launch_bounds__(64 * KF_WAVES, 8) void kminmer_kernel_fast(
     if (lane == 0 && xacc) atomicXor((unsigned long long *)&xor_shards[t & (XOR_SHARDS - 1)], (unsigned long long)xacc);
 }
 
-// ---- fused path: the k-min-mers whose k minimizers lie in more than one tile --------------------------------------------
-// The tiled kernel (FUSED) writes every window that lies inside one tile and leaves, per tile, an edge record: (G, p) of the
-// tile, its first k-1 minimizers {hash, jend} and its last k-1 minimizers {hash, j}.  A window that ENDS at minimizer i < k-1
-// of tile T's first read segment exists iff p + i >= k-1 (src/lib.rs:235: k minimizers of the same read); its first k-1-i
-// members are the last ones of the tiles before T (a tile that is one stretch of the same read hands on to the tile before
-// it).  One thread per (tile, i); output offset = G(T) + i - (k-1-p): the windows ending in T before it.
-__global__ __launch_bounds__(256) void fused_fixup_kernel(uint64_t n_tiles, Fused fz, const Counts *__restrict__ counts) {
-    const uint32_t k = fz.k, K1 = k - 1;
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t T = gid / K1;
-    const uint32_t i = (uint32_t)(gid % K1);
-    uint64_t hmin = 0;
-    bool emit = false;
-    if (T < n_tiles && !counts->need_unfused && !counts->bad_input) {
-        const uint32_t stride = edge_stride(k);
-        const uint8_t *e = fz.edge + T * (uint64_t)stride;
-        const EdgeHdr h = *reinterpret_cast<const EdgeHdr *>(e);
-        if (i < h.n_head && h.p_in + i >= K1) {
-            const EdgeRec *head = reinterpret_cast<const EdgeRec *>(e + sizeof(EdgeHdr));
-            uint64_t F = 0, Rv = 0;
-            uint32_t start = 0;
-            // members 0 .. need-1 of the window come from the tiles before T, walked backwards; member m adds
-            // rotl(mix(hash), k-1-m) to F and rotl(mix(hash), m) to Rv (src/lib.rs:275-288)
-            const uint32_t need = K1 - i;
-            uint32_t got = 0;
-            uint64_t Tb = T;
-            while (got < need && Tb > 0) {
-                Tb--;
-                const uint8_t *eb = fz.edge + Tb * (uint64_t)stride;
-                const EdgeHdr hb = *reinterpret_cast<const EdgeHdr *>(eb);
-                const EdgeRec *tail = reinterpret_cast<const EdgeRec *>(eb + sizeof(EdgeHdr)) + K1;
-                const uint32_t take = need - got < hb.n_tail ? need - got : hb.n_tail;
-                for (uint32_t q = 0; q < take; q++) {
-                    const EdgeRec rc = tail[hb.n_tail - 1 - q];
-                    const uint32_t m = need - 1 - got - q;
-                    const uint64_t x = mix32(rc.hash);
-                    F ^= rotl64(x, K1 - m);
-                    Rv ^= rotl64(x, m);
-                    if (m == 0) start = rc.pos;
-                }
-                got += take;
-                if (!(hb.flags & 1u)) break; // that tile's last segment began inside it: nothing of the read lies further back
-            }
-            if (got == need) { // (always: p counted these minimizers)
-                for (uint32_t q = 0; q <= i; q++) {
-                    const uint32_t m = need + q;
-                    const uint64_t x = mix32(head[q].hash);
-                    F ^= rotl64(x, K1 - m);
-                    Rv ^= rotl64(x, m);
-                }
-                hmin = F < Rv ? F : Rv;
-                emit = true;
-                const uint64_t o = h.g_excl + (uint64_t)(i - (K1 - h.p_in));
-                if (o < fz.km_capacity) {
-                    if (fz.o_hash) fz.o_hash[o] = hmin;
-                    if (fz.o_start) fz.o_start[o] = start;
-                    if (fz.o_end) fz.o_end[o] = head[i].pos;
-                    if (fz.o_rev) fz.o_rev[o] = (uint8_t)(Rv < F);
-                }
-            }
-        }
-    }
-    uint64_t x = emit ? hmin : 0;
-    for (int o = 32; o > 0; o >>= 1) x ^= __shfl_xor(x, o);
-    if ((threadIdx.x & 63) == 0 && x) atomicXor((unsigned long long *)&fz.xor_shards[(gid >> 6) & (XOR_SHARDS - 1)], (unsigned long long)x);
-}
-
 } // namespace
-
-hipError_t launch_fused_fixup(uint64_t n_tiles, Fused fz, const Counts *counts, hipStream_t st) {
-    if (n_tiles == 0 || fz.k <= 1) return hipSuccess; // k == 1: every k-min-mer is one minimizer, nothing spans tiles
-    const uint64_t threads = n_tiles * (uint64_t)(fz.k - 1);
-    hipLaunchKernelGGL(fused_fixup_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, n_tiles, fz, counts);
-    return hipGetLastError();
-}
 
 hipError_t launch_kminmers(uint64_t n_tiles, const uint64_t *tile_rec_off, const uint32_t *tile_cnt,
                            const uint64_t *tile_goff, Records rec, const uint64_t *mn_off, const uint64_t *km_off,

@@ -61,7 +61,7 @@ namespace {
 #define S2K_TW 12
 #endif
 constexpr int TW = S2K_TW;                                 // waves per block = all the waves of a CU (three per SIMD): ONE block per CU shares the two seed
-                                                       // tables, which leaves every wave ~1 KB more LDS than three blocks of four did (fused emission needs it)
+                                                       // tables (4 KiB once instead of three times)
 constexpr int HS_OFF = 16;                             // data starts here; byte HS_OFF-1 absorbs "slot -1" stores
 constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window slack
 constexpr int CAPP = 16;                               // positions per capture piece
@@ -78,9 +78,10 @@ constexpr int JOBCAP = S2K_JOBCAP;                             // queued hash re
 constexpr int REG_LA = 1;
 constexpr int HPC_LA = 2;                              // seed look-ahead (positions) of the Hpc hash loop: 8 spills there
 constexpr int NBL = 32;                                // read starts of a tile kept in LDS (hb / rs16); tiles with more search the read table
-constexpr int KMAX_FUSED = 32;                         // largest k the fused single-pass emission handles (ring of 64 + k - 1 mixed hashes)
-constexpr int LB_POLL_LIMIT = 1 << 16;                 // look-back polls (~2 us each) before a wave gives up and the host re-runs unfused
-constexpr int STORES_PER_ROUND = 3;                    // vector-memory operations one round of 64 hits issues (j, jend, rid): the counted vmcnt wait relies on it
+// vector-memory operations one round of 64 hits issues: the counted vmcnt wait relies on it (tools/isa/check_vmcnt.py checks it).
+// Descriptor path: one store ({offset in the tile, span}); legacy path: three (j, jend, read index).
+template <bool DESC> constexpr int stores_per_round() { return DESC ? 1 : 3; }
+static_assert(NBL == META_SEGS, "TileMeta keeps NBL segment starts");
 constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
 
 struct HpcLds {
@@ -91,33 +92,21 @@ struct HpcLds {
 };
 struct NoHpcLds {};
 
-struct FusedLds {
-    uint32_t hv[LISTCAP];    // fused emission: 32-bit hash of every hit of the batch (written by the listing lanes and the re-derivation)
-    int32_t segadj[NBL];     // per read segment s of the tile: (windows ending before the segment) - (hits before it) - (hits of the segment that end no window)
-    uint16_t segb[NBL];      // ... and the number of hits before the segment
-};
-struct NoFusedLds {};
-
-template <bool HPC, bool FUSED>
-struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type, std::conditional<FUSED, FusedLds, NoFusedLds>::type {
+template <bool HPC>
+struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
     uint8_t buf[BUF_BYTES];
-    union {
-        struct {
-            uint16_t list[LISTCAP];   // validated hits of the current batch: tile-local hash position (bits 0-13), ascending; bit 15 = hash must be re-derived
-            uint16_t jobx[JOBCAP];    // hits whose hash must be re-derived: tile-local position ...
-            uint16_t jobslot[JOBCAP]; // ... and index of the hit among the tile's hits
-        };
-        uint64_t ring[FUSED ? 64 + KMAX_FUSED : 1]; // fused emission, once the list is dead: mixed hashes of the round's 64 hits behind the k-1 before them
-    };
+    uint16_t list[LISTCAP];   // validated hits of the current batch: tile-local hash position (bits 0-13), ascending; bit 15 = hash must be re-derived
+    uint16_t jobx[JOBCAP];    // hits whose hash must be re-derived: tile-local position ...
+    uint16_t jobslot[JOBCAP]; // ... and index of the hit among the tile's hits
     int16_t hb[NBL];         // read starts inside the tile, as hash-space positions (ascending; 0 .. TILE_BASES)
     uint16_t rs16[NBL];      // rs16[i] = read_off[r0 + i] - t0 for the read starts inside the tile (i >= 1; read r0 starts at rs0, kept in a register)
 };
 constexpr int TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c], l-1)};  OUT table at 2048: {rotl(h[c], l), rotr(rc[c], 1)}
-template <bool HPC, bool FUSED>
-constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC, FUSED>); }
+template <bool HPC>
+constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>); }
 // one block of TW = 12 waves per CU: it may use the whole 160 KiB (MI355X_MICROARCH.md: "a single workgroup may declare all 160 KiB")
 #ifndef S2K_EXPERIMENT
-static_assert(block_lds_bytes<true, true>() <= 160 * 1024, "the block of a CU must fit its 160 KiB of LDS");
+static_assert(block_lds_bytes<true>() <= 160 * 1024, "the block of a CU must fit its 160 KiB of LDS");
 #endif
 
 // inclusive scan over the 64 lanes with DPP row shifts / broadcasts (no LDS round trips)
@@ -602,150 +591,23 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
     raw_e = y_in ? TILE_T * lo2 + decode(w2, n2) : he;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fused path: the look-backs over the tile / group descriptors (TileDesc, GroupDesc in s2k_dev.h).  Wave-uniform control
-// flow; lane i looks at one descriptor.  `polls` counts the rounds that found something missing; false = gave up.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t ld_desc(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_desc(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
-}
-__device__ __forceinline__ bool lb_wait(uint32_t &polls) {
-    if (++polls > (uint32_t)LB_POLL_LIMIT) return false;
-    __builtin_amdgcn_s_sleep(8);
-    return true;
-}
-// p of tile t: min(k-1, minimizers the read that continues into t has in the tiles before it).  Walks back over the a words:
-// a tile that holds a read start (or starts / ends with one) fixes p to its q, a tile that is one stretch of the read adds
-// its minimizers; the walk ends at the first of the former, or as soon as k-1 are counted.
-__device__ __forceinline__ bool p_lookback(const TileDesc *desc, uint64_t t, int lane, uint32_t K1, uint32_t &polls, uint32_t &p_out, bool &poison) {
-    uint32_t carried = 0; // minimizers of the stretch tiles of the windows already walked
-    int64_t hi = (int64_t)t - 1;
-    for (;;) {
-        const int64_t idx = hi - lane;
-        const unsigned long long a = idx >= 0 ? ld_desc(&desc[idx].a) : TD_VALID; // before tile 0: a read start, q = 0
-        const bool valid = (a & TD_VALID) != 0, passt = (a & TD_PASS) != 0;
-        const uint32_t contrib = valid ? (passt ? (uint32_t)(a & 0x3FFFu) : (uint32_t)(a >> 14) & 63u) : 0u;
-        const uint32_t sc = wave_incl_scan(contrib, lane); // lanes 0 .. i: the stretch tiles' minimizers, then the q of the tile that ends the walk
-        const uint64_t inval = __ballot(!valid), stop = __ballot(valid && !passt), full = __ballot(valid && carried + sc >= K1);
-        const int first_inval = inval ? __builtin_ctzll(inval) : 64;
-        const int first_stop = stop ? __builtin_ctzll(stop) : 64, first_full = full ? __builtin_ctzll(full) : 64;
-        const int e = first_stop < first_full ? first_stop : first_full;
-        if (e < first_inval) { // everything up to the deciding tile is known
-            const uint32_t v = carried + bcast(sc, e);
-            p_out = v < K1 ? v : K1;
-            poison = poison || (__ballot((a & TD_POISON) != 0) & ((2ull << e) - 1ull)) != 0;
-            return true;
-        }
-        if (first_inval < 64) { // a tile in between has not published yet
-            if (!lb_wait(polls)) return false;
-            continue;
-        }
-        carried += bcast(sc, 63); // 64 stretch tiles with fewer than k-1 minimizers in all (very sparse): further back
-        hi -= 64;
-    }
-}
-// The closer of group g (the group's last tile) knows its own (W, N); it adds the b words of the group's earlier tiles,
-// publishes the group sums, finds the totals before the group by a look-back over the groups and publishes the inclusive
-// totals.  Returns the totals BEFORE the group in Gx / Gmnx.
-__device__ __forceinline__ bool close_group(const TileDesc *desc, GroupDesc *gdesc, uint64_t t, int lane, uint32_t myW, uint32_t myN, bool mypoison,
-                                            uint32_t &polls, uint64_t &Gx, uint64_t &Gmnx, uint32_t &Wbefore, uint32_t &Nbefore, bool &poison) {
-    const uint64_t g = t / TILE_GROUP;
-    const int mine = (int)(t % TILE_GROUP); // tiles g*64 .. t-1 are lanes 0 .. mine-1
-    constexpr unsigned long long M48 = (1ull << 48) - 1ull;
-    unsigned long long bw;
-    for (;;) {
-        bw = lane < mine ? ld_desc(&desc[g * TILE_GROUP + lane].b) : TD_VALID;
-        if (__ballot((bw & TD_VALID) == 0) == 0) break;
-        if (!lb_wait(polls)) return false;
-    }
-    poison = poison || mypoison || __ballot((bw & TD_POISON) != 0) != 0;
-    const uint32_t wl = lane < mine ? (uint32_t)(bw & 0xFFFFFu) : 0u, nl = lane < mine ? (uint32_t)(bw >> 20) & 0x3FFFu : 0u;
-    Wbefore = bcast(wave_incl_scan(wl, lane), 63);
-    Nbefore = bcast(wave_incl_scan(nl, lane), 63);
-    const uint64_t gW = (uint64_t)Wbefore + myW, gN = (uint64_t)Nbefore + myN;
-    if (lane == 0) st_desc(&gdesc[g].gb, TD_VALID | (poison ? TD_POISON : 0ull) | gW | (gN << 28));
-    // look-back over the groups
-    uint64_t accW = 0, accN = 0;
-    int64_t hi = (int64_t)g - 1;
-    for (;;) {
-        const int64_t idx = hi - lane;
-        unsigned long long gb = TD_VALID, p0 = TD_VALID, p1 = TD_VALID; // before group 0: totals 0
-        if (idx >= 0) {
-            gb = ld_desc(&gdesc[idx].gb);
-            p0 = ld_desc(&gdesc[idx].gp0);
-            p1 = ld_desc(&gdesc[idx].gp1);
-        }
-        const uint64_t pre_ok = __ballot((p0 & TD_VALID) != 0 && (p1 & TD_VALID) != 0), gb_ok = __ballot((gb & TD_VALID) != 0);
-        const int jp = pre_ok ? __builtin_ctzll(pre_ok) : 64;
-        const uint64_t need = jp >= 64 ? ~0ull : ((1ull << jp) - 1ull);
-        if ((gb_ok & need) != need) {
-            if (!lb_wait(polls)) return false;
-            continue;
-        }
-        poison = poison || (__ballot((gb & TD_POISON) != 0) & need) != 0;
-        const bool in = lane < jp;
-        // (two 32-bit scans per quantity: a group's sums stay below 2^28, 64 of them below 2^34)
-        const uint32_t w_lo = in ? (uint32_t)(gb & 0xFFFFFFFu) : 0u, n_lo = in ? (uint32_t)(gb >> 28) & 0xFFFFFFFu : 0u;
-        accW += (uint64_t)bcast(wave_incl_scan(w_lo & 0xFFFFu, lane), 63) + ((uint64_t)bcast(wave_incl_scan(w_lo >> 16, lane), 63) << 16);
-        accN += (uint64_t)bcast(wave_incl_scan(n_lo & 0xFFFFu, lane), 63) + ((uint64_t)bcast(wave_incl_scan(n_lo >> 16, lane), 63) << 16);
-        if (jp < 64) {
-            const uint64_t q0 = readlane64(p0, jp), q1 = readlane64(p1, jp);
-            poison = poison || (q0 & TD_POISON) != 0;
-            Gx = (q0 & M48) + accW;
-            Gmnx = (q1 & M48) + accN;
-            break;
-        }
-        hi -= 64;
-    }
-    if (lane == 0) {
-        st_desc(&gdesc[g].gp0, TD_VALID | (poison ? TD_POISON : 0ull) | (Gx + gW));
-        st_desc(&gdesc[g].gp1, TD_VALID | (Gmnx + gN));
-    }
-    return true;
-}
-// k-min-mers / minimizers before tile t: the inclusive totals of the group before t's, plus the b words of the earlier tiles
-// of t's own group.
-__device__ __forceinline__ bool g_lookback(const TileDesc *desc, const GroupDesc *gdesc, uint64_t t, int lane, uint32_t &polls, uint64_t &G,
-                                           uint64_t &Gmn, bool &poison) {
-    const uint64_t g = t / TILE_GROUP;
-    const int mine = (int)(t % TILE_GROUP);
-    constexpr unsigned long long M48 = (1ull << 48) - 1ull;
-    unsigned long long bw, p0, p1;
-    for (;;) {
-        bw = lane < mine ? ld_desc(&desc[g * TILE_GROUP + lane].b) : TD_VALID;
-        p0 = g ? ld_desc(&gdesc[g - 1].gp0) : TD_VALID;
-        p1 = g ? ld_desc(&gdesc[g - 1].gp1) : TD_VALID;
-        if (__ballot((bw & TD_VALID) == 0 || (p0 & TD_VALID) == 0 || (p1 & TD_VALID) == 0) == 0) break;
-        if (!lb_wait(polls)) return false;
-    }
-    poison = poison || __ballot(((bw | p0) & TD_POISON) != 0) != 0;
-    const uint32_t wl = lane < mine ? (uint32_t)(bw & 0xFFFFFu) : 0u, nl = lane < mine ? (uint32_t)(bw >> 20) & 0x3FFFu : 0u;
-    G = (readlane64(p0, 0) & M48) + bcast(wave_incl_scan(wl, lane), 63);
-    Gmn = (readlane64(p1, 0) & M48) + bcast(wave_incl_scan(nl, lane), 63);
-    return true;
-}
-
-// Dense phase of one tile: hit bitmasks -> validated, ordered minimizers.
-//  * FUSED = false: minimizer records (j, jend, hash, read) go to the tile's slab; returns their number and sets `base`
-//    (tile_rec_off); a second kernel (s2k_kminmer.hip) turns them into k-min-mers.
-//  * FUSED = true: the k-min-mers themselves are written, at their final place: every window of k consecutive minimizers that
-//    lies inside the tile (src/lib.rs:231-266, closed form :275-288), at offset G + (windows ending earlier in the tile), G
-//    from the look-back above; km_off of the reads that start in the tile; the tile's first / last k-1 minimizers go to its
-//    edge record, from which fused_fixup_kernel emits the windows that span tiles.
-template <int L, bool HPC, bool FUSED, class WL, class IssueNext>
+// Dense phase of one tile: hit bitmasks -> validated, ordered minimizer records in the tile's slab.  Returns their number
+// and sets `base` (the slab, or a piece of the overflow region).
+//  * DESC = true (default path): 8 bytes per minimizer -- the 32-bit hash and {offset of the l-mer's first base inside the
+//    tile : 14, span to its last base : 18} -- plus the tile's descriptor word and its list of read segments (TileMeta); read
+//    positions and k-min-mers are made from these by s2k_desc.hip.
+//  * DESC = false (legacy path, k > 32 or tiles with more than 30 read starts): 16 bytes -- j, jend, hash, read index -- and a
+//    per-read minimizer count; s2k_kminmer.hip does the rest with per-read scans.
+template <int L, bool HPC, bool DESC, class WL, class IssueNext>
 __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, const uint8_t *D, const uint2 *tab,
-                                                const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_tiles, uint64_t t,
+                                                const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t t,
                                                 uint64_t t0, uint32_t tile_len, uint32_t nh, uint32_t halo_n,
                                                 uint32_t Tq, uint32_t l, uint32_t r0, uint32_t r1, uint64_t bpos0,
                                                 uint64_t rs0, int lane, const Records &rec, uint64_t *pool_cursor,
-                                                uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem, const Fused &fz,
-                                                bool &dma_waited,
+                                                uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem,
+                                                unsigned long long *__restrict__ d_agg, TileMeta *__restrict__ d_meta, uint32_t K1,
                                                 const uint32_t (&caps)[NPC], const uint32_t (&raw)[5], uint64_t *ph,
                                                 uint64_t &stamp) {
-    uint64_t xacc = 0;     // fused: XOR of the k-min-mer hashes this lane wrote for this tile (whole-run checksum, s2k_counts.xor_hash)
-    uint32_t lb_polls = 0; // fused: look-back polls of this tile (diagnostics)
     // (1) read starts that matter for this tile -> hash-space boundaries HB; an l-mer x is invalid iff
     //     some boundary has HB - w <= x <= HB - 1  (w = l-1 raw positions for Regular: the l-mer must end
     //     before the next read, src/lib.rs:215-230; w = l run heads for Hpc: head x+l must exist in the
@@ -895,27 +757,26 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     const uint32_t incl = wave_incl_scan(cnt, lane);
     const uint32_t myoff = incl - cnt;
     const uint32_t N = bcast(incl, 63); // valid minimizers of this tile
-    base = 0;
-    if constexpr (!FUSED) {
-        base = t * rec.slab_cap;
-        if (N == 0) {
+    base = t * rec.slab_cap;
+    bool dropped = false; // no room for the tile's records: the host re-runs with a larger pool
+    if (N > rec.slab_cap) { // rare: more hits than the per-tile slab holds
+        uint64_t got = 0;
+        if (lane == 0) got = atomicAdd((unsigned long long *)pool_cursor, (unsigned long long)N);
+        got = ((uint64_t)bcast((uint32_t)(got >> 32), 0) << 32) | bcast((uint32_t)got, 0);
+        base = rec.ovf_base + got;
+        if (base + N > rec.capacity) { // overflow region exhausted: the host re-runs with pool_needed
+            if (lane == 0) {
+                counts->pool_overflow = 1;
+                atomicMax((unsigned long long *)&counts->pool_needed, (unsigned long long)(got + N));
+            }
+            base = 0;
+            dropped = true;
+        }
+    }
+    if constexpr (!DESC) {
+        if (N == 0 || dropped) {
             issue_next(0u, base);
             return 0;
-        }
-        if (N > rec.slab_cap) { // rare: more hits than the per-tile slab holds
-            uint64_t got = 0;
-            if (lane == 0) got = atomicAdd((unsigned long long *)pool_cursor, (unsigned long long)N);
-            got = ((uint64_t)bcast((uint32_t)(got >> 32), 0) << 32) | bcast((uint32_t)got, 0);
-            base = rec.ovf_base + got;
-            if (base + N > rec.capacity) { // overflow region exhausted: the host re-runs with pool_needed
-                if (lane == 0) {
-                    counts->pool_overflow = 1;
-                    atomicMax((unsigned long long *)&counts->pool_needed, (unsigned long long)(got + N));
-                }
-                base = 0;
-                issue_next(0u, base);
-                return 0;
-            }
         }
     }
     // per-read minimizer counts, once per tile: read r0+i owns the hits in [HB[i-1], HB[i]) -- lane i keeps the count of
@@ -946,128 +807,45 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             }
             below_prev = below;
         }
-        if constexpr (!FUSED)
+        if constexpr (!DESC)
             if ((uint32_t)lane <= nb && mine) atomicAdd(&mn_cnt[r0 + lane], mine);
     }
-    // ---- fused: what the tile does to p, published before anything else is done with the hits -----------------------------
-    const uint32_t K1 = FUSED ? fz.k - 1u : 0u;
-    const bool dep = !(t0 == 0 || rs0 == t0); // a read that began before the tile continues into it
-    uint32_t m_first = 0, m_last = 0, Cfix = 0, q_out = 0, n_head = 0, n_tail = 0;
-    bool pass = false;
-    uint8_t *const edge = FUSED ? fz.edge + t * (uint64_t)edge_stride(fz.k) : nullptr;
-    const bool closer = FUSED && ((t + 1) % TILE_GROUP == 0 || t + 1 == n_tiles); // the last tile of its group of 64
-    uint64_t G = 0, Gmn = 0;
-    uint32_t p_in = 0, Wt = 0;
-    bool poisoned = false, have_g = false;
-    auto give_up = [&]() { // a poll ran out (or this tile cannot be handled): poison what follows, the host re-runs unfused
-        poisoned = true;
-        if (lane == 0) {
-            counts->need_unfused = 1;
-            st_desc(&fz.desc[t].a, TD_VALID | TD_POISON);
-            st_desc(&fz.desc[t].b, TD_VALID | TD_POISON);
-            if (closer) {
-                st_desc(&fz.gdesc[t / TILE_GROUP].gb, TD_VALID | TD_POISON);
-                st_desc(&fz.gdesc[t / TILE_GROUP].gp0, TD_VALID | TD_POISON);
-                st_desc(&fz.gdesc[t / TILE_GROUP].gp1, TD_VALID | TD_POISON);
-            }
-        }
-    };
-    if constexpr (FUSED) {
-        if (many) { // reads shorter than ~300 bases: more read starts than the LDS lists hold -- not handled by this path
-            give_up();
+    if constexpr (DESC) {
+        // ---- the tile's descriptor word and its read segments (see s2k_dev.h) ---------------------------------------------
+        if (many) { // more read starts than the lists hold (reads shorter than ~300 bases): the whole call takes the legacy path
+            if (lane == 0) counts->need_legacy = 1;
             issue_next(0u, base);
             return 0;
         }
-        m_first = bcast(mine, 0);
-        m_last = bcast(mine, (int)nb);
+        const bool dep = !(t0 == 0 || rs0 == t0); // a read that began before the tile continues into it
+        const uint32_t m_first = bcast(mine, 0), m_last = bcast(mine, (int)nb);
         uint32_t wfix = (uint32_t)lane <= nb && mine > K1 ? mine - K1 : 0u; // windows of a segment that starts a read in (or at the start of) the tile
         if (lane == 0 && dep) wfix = 0;                                         // (the first segment's depend on p)
-        Cfix = bcast(wave_incl_scan(wfix, lane), 63);
-        pass = dep && nb == 0 && !ext_at_end;
-        q_out = ext_at_end ? 0u : (m_last < K1 ? m_last : K1);
-        n_head = dep ? (m_first < K1 ? m_first : K1) : 0u;
-        n_tail = ext_at_end ? 0u : (m_last < K1 ? m_last : K1);
-        if (lane == 0) st_desc(&fz.desc[t].a, TD_VALID | (pass ? TD_PASS : 0ull) | ((unsigned long long)q_out << 14) | m_first);
-    }
-    // fused, step 2 (after the hashes of the hits are settled): p of this tile from the a words before it, hence W = k-min-mers
-    // ending in the tile; publish b; the closer of a group also publishes the group's sums and totals
-    auto publish_b = [&]() {
-        if (dep) {
-            if (!p_lookback(fz.desc, t, lane, K1, lb_polls, p_in, poisoned)) return give_up();
-        }
-        Wt = Cfix + (dep && m_first + p_in > K1 ? m_first + p_in - K1 : 0u);
-        if (lane == 0) st_desc(&fz.desc[t].b, TD_VALID | (poisoned ? TD_POISON : 0ull) | Wt | ((unsigned long long)N << 20));
-        if (closer) {
-            uint64_t Gx = 0, Gmnx = 0;
-            uint32_t wb = 0, nbf = 0;
-            if (!close_group(fz.desc, fz.gdesc, t, lane, Wt, N, poisoned, lb_polls, Gx, Gmnx, wb, nbf, poisoned)) return give_up();
-            G = Gx + wb;
-            Gmn = Gmnx + nbf;
-            have_g = true;
-        }
-    };
-    // fused, step 4 (as late as possible): G of this tile, then everything that follows from it: the edge header, per-segment
-    // output offsets, km_off of the reads that start here
-    auto resolve = [&]() {
-        if (!poisoned && !have_g) {
-            if (!g_lookback(fz.desc, fz.gdesc, t, lane, lb_polls, G, Gmn, poisoned)) give_up();
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70); // every vector-memory operation so far, the next tile's LDS-DMA loads included, is done
-        dma_waited = true;
-        if (poisoned && lane == 0) counts->need_unfused = 1;
-        const uint32_t skip = lane == 0 ? (dep ? K1 - p_in : K1) : K1; // minimizers of a segment that end no k-min-mer
-        const uint32_t wseg = (uint32_t)lane <= nb && mine > skip ? mine - skip : 0u;
-        const uint32_t winc = wave_incl_scan(wseg, lane);
-        const uint32_t Wb = winc - wseg; // (bcast(winc, 63) == Wt)
+        const uint32_t Cfix = bcast(wave_incl_scan(wfix, lane), 63);
+        const bool pass = dep && nb == 0 && !ext_at_end;
+        const uint32_t q_out = ext_at_end ? 0u : (m_last < K1 ? m_last : K1);
         if (lane == 0) {
-            EdgeHdr h;
-            h.g_excl = G;
-            h.p_in = p_in;
-            h.n_head = n_head;
-            h.n_tail = n_tail;
-            h.flags = pass ? 1u : 0u;
-            h.pad = 0;
-            *reinterpret_cast<EdgeHdr *>(edge) = h;
+            d_agg[t] = agg_pack(m_first, Cfix, dropped ? 0u : N, q_out, dep, pass);
+            TileMeta *m = &d_meta[t];
+            m->rec_base = base;
+            m->rs0 = rs0;
+            m->r0 = r0;
+            m->nb = (uint16_t)nb;
+            m->nrd = (uint16_t)(r1 - r0);
         }
-        if constexpr (FUSED) { // (the lambda is instantiated for both paths; only the fused LDS layout has these)
-            if ((uint32_t)lane <= nb) {
-                S.segadj[lane] = (int32_t)Wb - (int32_t)segstart - (int32_t)skip;
-                S.segb[lane] = (uint16_t)segstart;
-            }
+        if ((uint32_t)lane <= nb) {
+            d_meta[t].segstart[lane] = (uint16_t)segstart;
+            if (lane) d_meta[t].rs16[lane] = S.rs16[lane];
         }
-        if (!poisoned) {
-            const uint32_t nrd = r1 - r0; // reads r0+1 .. r1 start in (t0, end of the tile]: the first nb inside, the rest exactly at the end
-            if (lane >= 1 && (uint32_t)lane <= nrd) {
-                fz.o_km_off[(uint64_t)r0 + lane] = (uint32_t)lane <= nb ? G + Wb : G + Wt;
-                if (fz.mn_capacity) fz.o_mn_off[(uint64_t)r0 + lane] = (uint32_t)lane <= nb ? Gmn + segstart : Gmn + N;
-            }
-            if (t == 0) // reads 0 .. r0 start at position 0
-                for (uint64_t r = lane; r <= (uint64_t)r0; r += 64) {
-                    fz.o_km_off[r] = 0;
-                    if (fz.mn_capacity) fz.o_mn_off[r] = 0;
-                }
-            if (t + 1 == n_tiles && lane == 0) {
-                fz.o_km_off[n_reads] = G + Wt;
-                if (fz.mn_capacity) fz.o_mn_off[n_reads] = Gmn + N;
-                fz.totals[0] = Gmn + N;
-                fz.totals[1] = G + Wt;
-            }
-        }
-        wave_sync();
-    };
-    if constexpr (FUSED) {
-        if (N == 0) {
+        if (N == 0 || dropped) {
             issue_next(0u, base);
-            publish_b();
-            resolve();
-            if (lane == 0 && lb_polls) atomicAdd(&counts->lb_polls[t & 63], lb_polls);
             return 0;
         }
     }
     uint32_t njobs = 0;
     // Re-derivation of queued hashes (closed form src/nthash_hpc.rs:144,168): FOUR lanes per job, each takes a quarter of the l
     // bases (two LDS round trips per pass of 16 jobs instead of eight per lane), partial hashes are XOR-ed across the quad by DPP.
-    auto flush_jobs = [&](uint32_t b0) {
+    auto flush_jobs = [&]() {
         wave_sync();
         const uint32_t part = (uint32_t)lane & 3u;
         const uint32_t per = (l + 3u) >> 2;          // bases per lane
@@ -1114,17 +892,11 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             r ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0xB1, 0xf, 0xf, false);
             f ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x4E, 0xf, 0xf, false);
             r ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x4E, 0xf, 0xf, false);
-            if (act && part == 0) {
-                if constexpr (FUSED) S.hv[S.jobslot[job] - b0] = f < r ? f : r;
-                else rec.hash[base + S.jobslot[job]] = f < r ? f : r;
-            }
+            if (act && part == 0) rec.hash[base + S.jobslot[job]] = f < r ? f : r;
         }
         njobs = 0;
         wave_sync();
     };
-    bool resolved = false;          // fused: the look-back has been done (once per tile, as late as possible)
-    uint32_t jprev = 0;             // fused: j of the hits of the previous round of 64 (window starts reach back k-1 hits)
-    uint64_t xcarry = 0;            // fused: mixed hashes of the last k-1 hits of the previous batch (lanes 0 .. k-2)
     // (3) batches of up to LISTCAP hits: lanes list their own hits (ascending), then every lane takes one hit.
     //     No global LOADS in here: a load would make the compiler drain the previous round's stores.
     // A tile with at most LISTCAP hits (all but low-complexity sequence) takes its own instantiation of the batch: no range test
@@ -1134,7 +906,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
         constexpr bool SINGLE = decltype(single_c)::value;
         wave_sync();
         // every lane lists its own hits and stores the kept hash of those that were the last raw hit of their piece
-        auto list_hits = [&]() {
+        {
             uint32_t k = myoff;
 #pragma unroll
             for (int d = 0; d < 5; d++) {
@@ -1149,17 +921,12 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                     const uint32_t hvk = (bit & 16) ? cap_hi : cap_lo;
                     if (SINGLE || (k >= b0 && k < b0 + LISTCAP)) {
                         S.list[k - b0] = (uint16_t)((Tq * lane + 32 * d + bit) | (later ? 0x8000u : 0u));
-                        if constexpr (FUSED) {
-                            S.hv[k - b0] = hvk; // (a re-derived hash overwrites it below)
-                        } else {
-                            if (!later && !(sem.dbg_skip & 16)) rec.hash[base + k] = hvk;
-                        }
+                        if (!later && !(sem.dbg_skip & 16)) rec.hash[base + k] = hvk;
                     }
                     k++;
                 }
             }
-        };
-        list_hits();
+        }
         wave_sync();
         S2K_STAMP(4); // scan + list
         const uint32_t bn = N - b0 < (uint32_t)LISTCAP ? N - b0 : (uint32_t)LISTCAP;
@@ -1186,16 +953,14 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                 const uint64_t done = __ballot(minej);
                 njobs += (uint32_t)__popcll(done);
                 jobs &= ~done;
-                if (jobs) flush_jobs(b0);
+                if (jobs) flush_jobs();
             }
         }
-        if (njobs) flush_jobs(b0);
+        if (njobs) flush_jobs();
         S2K_STAMP(12); // hash re-derivation
         if (b0 + (uint32_t)LISTCAP >= N) issue_next(N, base);
-        if constexpr (FUSED)
-            if (b0 == 0) publish_b();
-        // one hit per lane: tile-local hash position -> stream positions of the l-mer's first base and of the last base that belongs
-        // to it, and the read it lies in (number of read starts at or before it, among those kept in LDS)
+        // one hit per lane: tile-local hash position -> stream positions of the l-mer's first base and of the last base that
+        // belongs to it
         auto backmap = [&](uint32_t x, uint64_t &p, uint64_t &e1) {
             if constexpr (HPC) {
                 uint32_t rp = 0, re = 0;
@@ -1210,11 +975,10 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                 e1 = p + l - 1; // src/lib.rs:226
             }
         };
-        if constexpr (!FUSED) {
         auto rounds = [&](auto many_c) {
         constexpr bool MANY = decltype(many_c)::value;
         for (uint32_t k0 = 0; k0 < bn; k0 += 64) {
-            // (markers for tools/isa/check_vmcnt.py: the loop body must issue the STORES_PER_ROUND vector-memory operations the
+            // (markers for tools/isa/check_vmcnt.py: the loop body must issue the stores_per_round() vector-memory operations the
             // counted wait at the top of the next tile relies on)
             asm volatile("; S2K_MARK round_begin many=%0" ::"i"(MANY ? 1 : 0));
             const uint32_t kk = k0 + lane;
@@ -1225,6 +989,15 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             uint64_t p = 0, e1 = 0; // stream position of the l-mer start; position of the last base that belongs to it
             if (act) backmap(x, p, e1);
             S2K_STAMP(9); // round: back-map
+            if constexpr (DESC) {
+                if (act) {
+                    // tile-relative record: where the read starts is looked up from the tile's segment list by the k-min-mer kernel
+                    const uint64_t span = e1 - p;
+                    if (span > (uint64_t)REC_SPAN_MAX) counts->need_legacy = 1; // (a homopolymer stretch of > 262 kbp inside one l-mer)
+                    const uint32_t sp = span > (uint64_t)REC_SPAN_MAX ? REC_SPAN_MAX : (uint32_t)span;
+                    if (!(sem.dbg_skip & 16)) rec.j[base + b0 + kk] = (uint32_t)(p - t0) | (sp << 14);
+                }
+            } else {
             if (act) {
                 uint64_t rstart;
                 if constexpr (!MANY) {
@@ -1260,117 +1033,22 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                     remm &= ~same;
                 }
             }
+            }
             asm volatile("; S2K_MARK round_end many=%0" ::"i"(MANY ? 1 : 0));
         }
         };
         // > NBL - 2 reads starting in one tile take the variant that searches the read table itself; keeping it a
         // separate instantiation keeps its global loads out of the common loop
-        if (many) rounds(std::true_type{});
-        else rounds(std::false_type{});
+        if constexpr (DESC) {
+            rounds(std::false_type{});
         } else {
-        // ---- fused: back-map rounds into registers, look-back, emission rounds --------------------------------------------
-        constexpr int NR = LISTCAP / 64;
-        uint32_t jv[NR], je[NR], cs[NR];
-#pragma unroll
-        for (int u = 0; u < NR; u++) {
-            jv[u] = je[u] = cs[u] = 0;
-            if (64u * u < bn) { // wave-uniform
-                const uint32_t kq = 64u * u + lane;
-                const bool act = kq < bn;
-                if (act) {
-                    const uint32_t x = S.list[kq] & 0x3FFFu;
-                    uint64_t p = 0, e1 = 0;
-                    backmap(x, p, e1);
-                    uint32_t c = 0;
-                    for (uint32_t i = 0; i < nb; i++) c += (S.hb[i] <= (int32_t)x); // wave-uniform trip count, LDS broadcast
-                    const uint64_t rstart = c == 0 ? rs0 : t0 + S.rs16[c];
-                    jv[u] = (uint32_t)(p - rstart);
-                    je[u] = (uint32_t)(e1 - rstart);
-                    cs[u] = c;
-                    // the tile's first / last k-1 minimizers, for the k-min-mers that span tiles (fused_fixup_kernel)
-                    const uint32_t i = b0 + kq;
-                    if (i < n_head) reinterpret_cast<EdgeRec *>(edge + sizeof(EdgeHdr))[i] = EdgeRec{S.hv[kq], je[u]};
-                    if (i + n_tail >= N) reinterpret_cast<EdgeRec *>(edge + sizeof(EdgeHdr))[K1 + (i + n_tail - N)] = EdgeRec{S.hv[kq], jv[u]};
-                }
-            }
-        }
-        S2K_STAMP(9); // back-map rounds
-        if (!resolved) {
-            resolve();
-            resolved = true;
-        }
-        S2K_STAMP(10); // look-back
-        if (!poisoned) {
-            const uint32_t k = fz.k;
-            if constexpr (!SINGLE)
-                if (b0 != 0 && (uint32_t)lane < K1) S.ring[lane] = xcarry; // (the list of this batch sat on the ring meanwhile)
-#pragma unroll
-            for (int u = 0; u < NR; u++) {
-                if (64u * u < bn) { // wave-uniform
-                    const uint32_t kq = 64u * u + lane;
-                    const bool act = kq < bn;
-                    const uint32_t i = b0 + kq; // index of the hit among the tile's minimizers
-                    const uint32_t h32 = act ? S.hv[kq] : 0u;
-                    const uint64_t xm = mix32(h32); // src/lib.rs:157-169
-                    wave_sync();
-                    S.ring[K1 + lane] = xm;
-                    wave_sync();
-                    const uint32_t sb = S.segb[cs[u]];
-                    const int32_t adj = S.segadj[cs[u]];
-                    // the window of k minimizers that ENDS at this hit lies inside the tile (and inside the read)
-                    const bool win = act && i - sb >= K1;
-                    uint64_t f = 0, r = 0;
-                    for (uint32_t m = 0; m < k; m++) { // ring[lane + m] = hit i - (k-1) + m
-                        const uint64_t xw = S.ring[lane + m];
-                        f = ((f << 1) | (f >> 63)) ^ xw; // F  = XOR rotl(x_m, k-1-m)   (src/lib.rs:238-249, closed form :275-288)
-                        r = ((r >> 1) | (r << 63)) ^ xw; // Rv = rotl(XOR rotr(x_m, k-1-m), k-1) = XOR rotl(x_m, m)
-                    }
-                    const uint64_t rvv = rotl64(r, K1);
-                    // start = j of the window's first minimizer: k-1 hits back, in this round or the one before it
-                    const uint32_t jsame = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - K1) & 63u) << 2, (int)jv[u]);
-                    const uint32_t jbefore = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - K1) & 63u) << 2, (int)jprev);
-                    const uint32_t jstart = (uint32_t)lane >= K1 ? jsame : jbefore;
-                    const uint64_t hmin = f < rvv ? f : rvv;
-                    if (win) {
-                        const uint64_t o = G + (uint64_t)(int64_t)((int32_t)i + adj);
-                        xacc ^= hmin;
-                        if (o < fz.km_capacity) {
-                            if (fz.o_hash) fz.o_hash[o] = hmin;
-                            if (fz.o_start) fz.o_start[o] = jstart;
-                            if (fz.o_end) fz.o_end[o] = je[u];
-                            if (fz.o_rev) fz.o_rev[o] = (uint8_t)(rvv < f); // src/lib.rs:250-251
-                        }
-                    }
-                    if (fz.mn_capacity && act) { // optional minimizer triples (NtHashHPCIterator::Item, src/nthash_hpc.rs:193)
-                        const uint64_t g = Gmn + i;
-                        if (g < fz.mn_capacity) {
-                            fz.o_mn_j[g] = jv[u];
-                            fz.o_mn_jend[g] = je[u];
-                            fz.o_mn_hash[g] = h32;
-                        }
-                    }
-                    wave_sync();
-                    if ((uint32_t)lane >= 64u - K1) S.ring[lane - (64u - K1)] = xm; // the last k-1 hits of a full round lead the next one
-                    jprev = jv[u];
-                }
-            }
-            if constexpr (!SINGLE) {
-                wave_sync();
-                if ((uint32_t)lane < K1) xcarry = S.ring[lane];
-            }
-        }
+            if (many) rounds(std::true_type{});
+            else rounds(std::false_type{});
         }
     };
     if (N <= (uint32_t)LISTCAP) batch(0u, std::true_type{});
     else
         for (uint32_t b0 = 0; b0 < N; b0 += LISTCAP) batch(b0, std::false_type{});
-    if constexpr (FUSED) { // one atomic per tile into one of 4096 shards
-        for (int o = 32; o > 0; o >>= 1) xacc ^= __shfl_xor(xacc, o);
-        if (lane == 0) {
-            if (xacc) atomicXor((unsigned long long *)&fz.xor_shards[t & (XOR_SHARDS - 1)], (unsigned long long)xacc);
-            if (lb_polls) atomicAdd(&counts->lb_polls[t & 63], lb_polls);
-        }
-    }
     return N;
 }
 
@@ -1378,16 +1056,15 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
 // While the rounds of a tile run, the next tile's 9344 bytes are in flight into the wave's LDS buffer (LDS-DMA), and the
 // read-table entries of the next tiles are fetched before they are needed, so no global-load latency sits on the critical
 // path except in the first iteration.
-// FUSED: the k-min-mers are written by this kernel (see dense_phase); the look-back needs every tile below a tile that is
-// being processed to be in some running wave's hands or finished: tiles are handed out in increasing order (the static three,
-// then the cursors, which a wave never changes) and the grid is exactly what is resident at once.
-template <int L, bool HPC, bool FUSED>
+// DESC: the descriptor path (8-byte records + one word and a segment list per tile, see dense_phase); else the legacy records.
+template <int L, bool HPC, bool DESC>
 __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
     uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
-    uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts, const Fused *fzp) {
+    uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts,
+    unsigned long long *__restrict__ d_agg, TileMeta *__restrict__ d_meta, uint32_t K1) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    using WL = WaveLdsT<HPC, FUSED>;
+    using WL = WaveLdsT<HPC>;
     uint2 *tab = reinterpret_cast<uint2 *>(smem);
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap(); // lut() assumes it
     const int lane0 = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: everything per tile is scalar
@@ -1473,10 +1150,6 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     // that wait -- every other load of the next tile's data is issued before the hash loop and waited for right after it --
     // and the wait leaves exactly that many operations in flight.
     uint32_t stores_after_dma = 0;
-    // FUSED: no counting -- the look-back of every tile ends in a full s_waitcnt vmcnt(0) that comes after the DMA loads were
-    // issued (dma_waited), so at the top of the next iteration they have landed; the k-min-mer stores issued after it are never
-    // waited for.  Only a tile whose loads went out after its look-back (more than LISTCAP hits) waits at the top.
-    bool dma_waited = false; // wave-uniform
     // tn / tnn: the next two tiles of this wave; >= n_tiles: none.  Dynamic tiles are numbered from dyn0 on: cursor g deals
     // dyn0 + g, dyn0 + g + TILE_CURSORS, ... (pool_cursor[16 + 16 g], zeroed by the host before the launch).
     uint64_t tn = t + n_waves, tnn = t + 2 * n_waves;
@@ -1509,18 +1182,14 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         if (__builtin_amdgcn_readfirstlane((int)have_pre)) { // a scalar branch: as a divergent if/else the slow path's loads would precede this wait
             // loaded into the buffer by the previous iteration (prologue: just now): wait for the loads, nothing to move.
             // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; 0x0F70 = vmcnt(0) only
-            if constexpr (FUSED) {
-                if (!dma_waited) __builtin_amdgcn_s_waitcnt(0x0F70);
-            } else {
-            static_assert(STORES_PER_ROUND == 3, "the cases below are 1 .. 4 rounds of STORES_PER_ROUND operations");
-            asm volatile("; S2K_MARK counted_wait per_round=%0" ::"i"(STORES_PER_ROUND));
+            constexpr int SPR = stores_per_round<DESC>();
+            asm volatile("; S2K_MARK counted_wait per_round=%0" ::"i"(SPR));
             switch (__builtin_amdgcn_readfirstlane((int)stores_after_dma)) { // wave-uniform, and the compiler should know
-                case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
-                case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
-                case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break;
-                case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
+                case 1 * SPR: __builtin_amdgcn_s_waitcnt(0x0F70 | (1 * SPR)); break;
+                case 2 * SPR: __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * SPR)); break;
+                case 3 * SPR: __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * SPR)); break;
+                case 4 * SPR: __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * SPR)); break;
                 default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-            }
             }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -1591,13 +1260,12 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         S2K_STAMP(1); // hpc compaction
         // ---- the next tile's bases: DMA into this wave's buffer, issued from inside the dense phase (see issue_once) -----
         auto issue_next = [&](uint32_t n_rec, uint64_t rec_base) {
-            if constexpr (!FUSED) {
+            if constexpr (!DESC) {
                 if (lane == 0) { // before the DMA loads: only the rounds' stores may follow them
                     tile_cnt[t] = n_rec;
                     tile_rec_off[t] = rec_base;
                 }
             }
-            dma_waited = false;
             have_pre = false;
             if (tn < n_tiles && is_full(tn)) {
                 prefetch(tn);
@@ -1646,24 +1314,12 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         // or is spilled -- across the hash loop, which is where the register pressure peaks.
         int lane_d = lane;
         asm volatile("" : "+v"(lane_d));
-        Fused fz{};
-        if constexpr (FUSED) {
-            // (through the constant address space: scalar loads; as ordinary global loads they land in VGPRs and get spilled)
-            typedef const __attribute__((address_space(4))) unsigned long long *c64_p;
-            c64_p fq = (c64_p)(uintptr_t)fzp;
-            asm volatile("" : "+s"(fq)); // opaque: keeps the loads from being hoisted out of the tile loop
-            static_assert(sizeof(Fused) % 8 == 0, "copied as 64-bit words");
-            unsigned long long fw[sizeof(Fused) / 8];
-#pragma unroll
-            for (size_t i = 0; i < sizeof(Fused) / 8; i++) fw[i] = fq[i];
-            __builtin_memcpy(&fz, fw, sizeof fz);
-        }
-        if (FUSED || (nh != 0 && sem.enabled)) { // (fused: every tile takes part in the look-back chain, hits or not)
+        if (DESC || (nh != 0 && sem.enabled)) { // (descriptor path: every tile leaves its word and its segment list, hits or not)
 #ifndef EXP_NODENSE
             if (!(sem.dbg_skip & 2))
-                N = dense_phase<L, HPC, FUSED>(issue_once, S, D, tab, read_off, n_reads, n_tiles, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1,
-                                            bpos0, rs0, lane_d, rec, pool_cursor, mn_cnt, counts, base, sem, fz, dma_waited,
-                                            caps, raw, ph, stamp);
+                N = dense_phase<L, HPC, DESC>(issue_once, S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1,
+                                           bpos0, rs0, lane_d, rec, pool_cursor, mn_cnt, counts, base, sem, d_agg, d_meta, K1,
+                                           caps, raw, ph, stamp);
 #endif
             S2K_STAMP(5); // rounds
         }
@@ -1673,7 +1329,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         {
             const bool many = (cr1 - cr0) > (uint32_t)(NBL - 2) || (sem.dbg_skip & 16) != 0; // (KNOBS builds: stores ablated)
             const uint32_t last = N == 0 ? 0u : N - ((N - 1) / (uint32_t)LISTCAP) * (uint32_t)LISTCAP;
-            stores_after_dma = many ? 0u : (uint32_t)STORES_PER_ROUND * ((last + 63u) / 64u);
+            stores_after_dma = many ? 0u : (uint32_t)stores_per_round<DESC>() * ((last + 63u) / 64u);
         }
         wave_sync(); // LDS of this wave is reused by the next tile
         r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn; prevb = prevbn; // rotate the pipeline
@@ -1718,12 +1374,12 @@ __global__ __launch_bounds__(256) void tile_index_kernel(const uint64_t *__restr
     tile_read0[t] = (uint32_t)lo;
 }
 
-template <int L, bool HPC, bool FUSED>
+template <int L, bool HPC, bool DESC>
 hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                            uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
-                           uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts, const Fused *d_fz) {
-    auto kern = tile_minimizer_kernel<L, HPC, FUSED>;
-    const int lds = block_lds_bytes<HPC, FUSED>();
+                           uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts, const Desc *desc) {
+    auto kern = tile_minimizer_kernel<L, HPC, DESC>;
+    const int lds = block_lds_bytes<HPC>();
     // per instantiation AND per device: function attributes and occupancy belong to the device the module is loaded on
     // (contexts on different threads may launch concurrently: the cache is filled under a lock)
     constexpr int MAX_DEV = 64;
@@ -1755,7 +1411,8 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
     const uint64_t resident = (uint64_t)n_cu * per_cu;
     if (blocks > resident) blocks = resident; // persistent: waves loop over the remaining tiles
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * TW), lds, st, bases, read_off, n_reads, n_bases, n_tiles,
-                       tile_read0, sem, rec, pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts, d_fz);
+                       tile_read0, sem, rec, pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts, desc ? desc->agg : nullptr,
+                       desc ? desc->meta : nullptr, desc ? desc->k - 1u : 0u);
     return hipGetLastError();
 }
 
@@ -1763,11 +1420,11 @@ template <int L>
 hipError_t launch_tiles_l(bool hpc, hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
                           uint64_t n_bases, uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec,
                           uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
-                          Counts *counts, const Fused *d_fused) {
+                          Counts *counts, const Desc *desc) {
 #define S2K_GO(H, F)                                                                                                       \
     launch_tiles_lh<L, H, F>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, tile_rec_off, \
-                             tile_cnt, mn_cnt, counts, d_fused)
-    if (d_fused) return hpc ? S2K_GO(true, true) : S2K_GO(false, true);
+                             tile_cnt, mn_cnt, counts, desc)
+    if (desc) return hpc ? S2K_GO(true, true) : S2K_GO(false, true);
     return hpc ? S2K_GO(true, false) : S2K_GO(false, false);
 #undef S2K_GO
 }

@@ -19,6 +19,6 @@ int main(void) {
            S2K_MODE_SIMD, S2K_MODE_HPCSIMD);
     printf("enum.S2K_FLAG_WANT_MINIMIZERS %u\nenum.S2K_FLAG_FORCE_SERIAL %u\nenum.S2K_FLAG_NO_PACK2 %u\nenum.S2K_HPC_RLE_ALPHABET %u\nenum.S2K_ABI_VERSION %d\n",
            (unsigned)S2K_FLAG_WANT_MINIMIZERS, (unsigned)S2K_FLAG_FORCE_SERIAL, (unsigned)S2K_FLAG_NO_PACK2, (unsigned)S2K_HPC_RLE_ALPHABET, S2K_ABI_VERSION);
-    printf("enum.S2K_ERR_NO_DEVICE %d\nenum.S2K_ERR_CAPACITY %d\nenum.S2K_FLAG_NO_FUSED %u\n", S2K_ERR_NO_DEVICE, S2K_ERR_CAPACITY, (unsigned)S2K_FLAG_NO_FUSED);
+    printf("enum.S2K_ERR_NO_DEVICE %d\nenum.S2K_ERR_CAPACITY %d\nenum.S2K_FLAG_LEGACY_PATH %u\n", S2K_ERR_NO_DEVICE, S2K_ERR_CAPACITY, (unsigned)S2K_FLAG_LEGACY_PATH);
     return 0;
 }

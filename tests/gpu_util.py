@@ -32,7 +32,7 @@ def compare(eng, oracle, reads, l, k, d, mode, force_serial=False, expect_path=N
     if expect_path is not None:
         # 0 = tiled kernel, fused single pass; 2 = tiled kernel + k-min-mer kernel (k > 32, or a tile with > 30 read starts):
         # a caller that expects "tiled" accepts both, "fused" / "two-kernel" / "serial" (1) are exact
-        ok = {0: (0, 2), "fused": (0,), "two-kernel": (2,), 1: (1,), 2: (2,)}[expect_path]
+        ok = {0: (0, 2), "desc": (0,), "legacy": (2,), 1: (1,), 2: (2,)}[expect_path]
         assert c["path"] in ok, ("path", ctx, c["path"])
     return got
 

@@ -76,7 +76,7 @@ def test_struct_layouts_match_header(tmp_path):
     assert facts["enum.S2K_HPC_RLE_ALPHABET"] == (pkg.HPC_RLE_ALPHABET,) and facts["enum.S2K_FLAG_NO_PACK2"] == (pkg.FLAG_NO_PACK2,)
     assert facts["enum.S2K_ABI_VERSION"] == (pkg.load_library().s2k_abi_version(),)
     assert facts["enum.S2K_ERR_NO_DEVICE"] == (8,) and facts["enum.S2K_ERR_CAPACITY"] == (7,)
-    assert facts["enum.S2K_FLAG_NO_FUSED"] == (pkg.FLAG_NO_FUSED,)
+    assert facts["enum.S2K_FLAG_LEGACY_PATH"] == (pkg.FLAG_LEGACY_PATH,)
 
 
 def test_kminmerhash_semantics():

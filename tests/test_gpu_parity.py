@@ -692,7 +692,7 @@ def test_baseline_config3_ont_like_lengths(eng, oracle):
     lens = _lognormal_lengths(rng, 160, 20000, 0.5, 1000, 200000)
     reads = [rand_read(rng, int(n), hp=0.15) for n in lens]
     for mode in SCALAR:
-        compare(eng, oracle, reads, 31, 10, 0.01, mode, expect_path="fused", tag="C3-ont")
+        compare(eng, oracle, reads, 31, 10, 0.01, mode, expect_path="desc", tag="C3-ont")
 
 
 def test_baseline_config4_hifi_like_hpc_backmap(eng, oracle):
@@ -710,9 +710,9 @@ def test_baseline_config4_hifi_like_hpc_backmap(eng, oracle):
         letters[1:] = (letters[:-1] + 1 + rng.integers(0, 3, size=n - 1)) % 4  # consecutive runs differ... mostly
         s = np.repeat(np.frombuffer(b"ACGT", dtype=np.uint8)[letters], runs)[:n]
         reads.append(s.tobytes())
-    got = compare(eng, oracle, reads, 31, 10, 0.01, HM.Hpc, expect_path="fused", tag="C4-hifi")
+    got = compare(eng, oracle, reads, 31, 10, 0.01, HM.Hpc, expect_path="desc", tag="C4-hifi")
     assert got["n"] > 0 and int((got["end"] - got["start"]).max()) > 500  # long runs really widen the spans
-    compare(eng, oracle, reads, 31, 10, 0.01, HM.Regular, expect_path="fused", tag="C4-hifi-regular")
+    compare(eng, oracle, reads, 31, 10, 0.01, HM.Regular, expect_path="desc", tag="C4-hifi-regular")
 
 
 def test_baseline_config5_mbp_contigs_sparse_density(eng, oracle):
@@ -721,7 +721,7 @@ def test_baseline_config5_mbp_contigs_sparse_density(eng, oracle):
     rng = np.random.default_rng(33)
     reads = [rand_read(rng, 1_000_000, hp=0.2) for _ in range(6)] + [rand_read(rng, 1_000_000)]
     for mode in SCALAR:
-        got = compare(eng, oracle, reads, 31, 10, 0.001, mode, expect_path="fused", tag="C5-contigs")
+        got = compare(eng, oracle, reads, 31, 10, 0.001, mode, expect_path="desc", tag="C5-contigs")
         assert got["counts"]["hash_bound"] == 4294967
 
 

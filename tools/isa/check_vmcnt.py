@@ -2,7 +2,8 @@
 """Checks the hand-counted `s_waitcnt vmcnt(n)` of the tiled kernel against the ISA the compiler emitted.
 
 The kernel loads the next tile with LDS-DMA (global_load_lds_dwordx4, inline asm) and, at the top of the next iteration, waits
-with vmcnt(n), n = STORES_PER_ROUND x (rounds of the last batch of hits): the vector-memory operations issued AFTER the DMA
+with vmcnt(n), n = stores_per_round() x (rounds of the last batch of hits; 1 store per round on the descriptor path, 3 on the
+legacy one): the vector-memory operations issued AFTER the DMA
 loads.  vmcnt counts loads, LDS-DMA loads and stores in order, so MORE operations after the DMA than counted only make the
 wait longer; FEWER would let it return before the tile has landed (stale LDS, silently wrong minimizers).  The kernel marks
 the body of its one-lane-per-hit round loop with `; S2K_MARK round_begin / round_end` comments; this script counts the
@@ -36,8 +37,7 @@ def check(path):
         errors.append("%s: no tile_minimizer_kernel instantiation found" % path)
     for name, a, b in funcs:
         short = re.search(r"tile_minimizer_kernelILi(\d+)ELb(\d)ELb(\d)", name)
-        tag = "L=%s hpc=%s fused=%s" % short.groups() if short else name
-        fused = bool(short) and short.group(3) == "1"
+        tag = "L=%s hpc=%s desc=%s" % short.groups() if short else name
         labels, branches, marks, need, dma, waits = {}, [], [], None, 0, set()
         for i in range(a, b):
             s = lines[i].strip()
@@ -58,15 +58,6 @@ def check(path):
             m = re.match(r"s_waitcnt vmcnt\((\d+)\)$", s)
             if m:
                 waits.add(int(m.group(1)))
-        if fused:
-            # the fused kernel counts nothing: its look-back ends in a full s_waitcnt vmcnt(0) after the DMA loads were issued, and
-            # the top of the next tile waits in full when that did not happen (dma_waited)
-            if need is not None or marks:
-                errors.append("%s: a counted wait in the fused kernel" % tag)
-            if dma < 10 or 0 not in waits:
-                errors.append("%s: %d LDS-DMA loads / no full vmcnt wait" % (tag, dma))
-            report.append("%s: no counted wait (full s_waitcnt vmcnt(0) after the look-back), %d LDS-DMA loads" % (tag, dma))
-            continue
         if need is None:
             errors.append("%s: no counted_wait marker" % tag)
             continue
