@@ -290,6 +290,7 @@ uint64_t slab_estimate(double density) {
     double mu = (double)TILE_BASES * (1.0 - (1.0 - d) * (1.0 - d));
     uint64_t cap = (uint64_t)(mu + 6.0 * sqrt(mu + 1.0)) + 32;
     cap = (cap + 15) & ~(uint64_t)15;
+    if (cap < 64) cap = 64; // (the descriptor path's k-min-mer kernel fetches a tile's first 64 records before it knows how many there are)
     if (cap > (uint64_t)TILE_BASES) cap = TILE_BASES;
     return cap;
 }

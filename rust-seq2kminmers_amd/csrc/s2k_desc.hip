@@ -15,20 +15,19 @@
 namespace s2k {
 namespace {
 
-constexpr int SCAN_CH = 16;       // tiles per thread in the chunk passes
-constexpr int SCAN_TOP = 1024;    // threads of the single block that scans the chunk words
 constexpr unsigned long long M48 = (1ull << 48) - 1ull;
 
 struct PairState { // (G, p) and the minimizer count beside G
     uint64_t G, Gmn;
     uint32_t p;
 };
-__device__ inline void apply(PairState &s, const AggF &a, uint32_t K1) {
+__device__ inline PairState applied(PairState s, const AggF &a, uint32_t K1) {
     s.G += agg_windows(a, s.p, K1);
     s.Gmn += a.N;
     s.p = agg_p(a, s.p, K1);
+    return s;
 }
-// chunk words: {m_f, C, N, q | dep << 8 | pass << 9}
+// words of the upper scan levels: {m_f, C, N, q | dep << 8 | pass << 9}; states: {G, Gmn, p}
 __device__ inline void st_agg(unsigned long long *w, const AggF &a) {
     w[0] = a.m_f;
     w[1] = a.C;
@@ -45,64 +44,106 @@ __device__ inline AggF ld_agg(const unsigned long long *w) {
     a.pass = ((w[3] >> 9) & 1u) != 0;
     return a;
 }
-
-__global__ __launch_bounds__(256) void desc_scan_chunks(const unsigned long long *__restrict__ agg, uint64_t n_tiles, uint32_t K1,
-                                                        unsigned long long *__restrict__ chunk_agg, const Counts *__restrict__ counts) {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t t0 = c * SCAN_CH;
-    if (t0 >= n_tiles || counts->need_legacy || counts->bad_input || counts->pool_overflow) return;
-    AggF a = agg_identity();
-    for (int i = 0; i < SCAN_CH && t0 + i < n_tiles; i++) a = agg_then(a, agg_unpack(agg[t0 + i]), K1);
-    st_agg(chunk_agg + 4 * c, a);
+template <bool PACKED>
+__device__ inline AggF ld_level(const unsigned long long *in, uint64_t i) { // level 0: the tiles' packed words; above: 32-byte words
+    if constexpr (PACKED) return agg_unpack(in[i]);
+    else return ld_agg(in + 4 * i);
 }
+__device__ inline uint64_t shfl_up64(uint64_t v, int o) {
+    return ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), o) << 32) | (uint32_t)__shfl_up((int)(uint32_t)v, o);
+}
+// inclusive scan of `a` over the 64 lanes under agg_then (lane i: lanes 0 .. i in order)
+__device__ inline AggF wave_scan_agg(AggF a, int lane, uint32_t K1) {
+    for (int o = 1; o < 64; o <<= 1) {
+        AggF b;
+        b.m_f = shfl_up64(a.m_f, o);
+        b.C = shfl_up64(a.C, o);
+        b.N = shfl_up64(a.N, o);
+        const uint32_t f = (uint32_t)__shfl_up((int)(a.q | (a.dep ? 256u : 0u) | (a.pass ? 512u : 0u)), o);
+        b.q = f & 63u;
+        b.dep = (f & 256u) != 0;
+        b.pass = (f & 512u) != 0;
+        if (lane >= o) a = agg_then(b, a, K1);
+    }
+    return a;
+}
+__device__ inline bool scan_off(const Counts *counts) { return counts->need_legacy || counts->bad_input || counts->pool_overflow; }
 
-// one block: thread i folds its share of the chunk words, thread 0 walks the SCAN_TOP partial results, then every thread walks
-// its share again and leaves the state at the start of every chunk
-__global__ __launch_bounds__(SCAN_TOP) void desc_scan_top(const unsigned long long *__restrict__ chunk_agg, uint64_t n_chunks, uint32_t K1,
-                                                          unsigned long long *__restrict__ chunk_state, const Counts *__restrict__ counts) {
-    __shared__ unsigned long long part[SCAN_TOP][4];
-    __shared__ unsigned long long start[SCAN_TOP][3];
-    if (counts->need_legacy || counts->bad_input || counts->pool_overflow) return;
-    const uint64_t per = (n_chunks + SCAN_TOP - 1) / SCAN_TOP;
-    const uint64_t c0 = per * threadIdx.x, c1 = c0 + per < n_chunks ? c0 + per : n_chunks;
-    AggF a = agg_identity();
-    for (uint64_t c = c0; c < c1; c++) a = agg_then(a, ld_agg(chunk_agg + 4 * c), K1);
-    st_agg(part[threadIdx.x], a);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        PairState s{0, 0, 0};
-        for (int i = 0; i < SCAN_TOP; i++) {
-            start[i][0] = s.G;
-            start[i][1] = s.Gmn;
-            start[i][2] = s.p;
-            apply(s, ld_agg(part[i]), K1);
+// one wave per 64 entries of a level: what the 64 together do (coalesced loads, log-step scan)
+template <bool PACKED>
+__global__ __launch_bounds__(256) void desc_scan_reduce(const unsigned long long *__restrict__ in, uint64_t n, uint32_t K1,
+                                                        unsigned long long *__restrict__ out, const Counts *__restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), i = c * 64 + lane;
+    if (c * 64 >= n || scan_off(counts)) return;
+    const AggF a = wave_scan_agg(i < n ? ld_level<PACKED>(in, i) : agg_identity(), lane, K1);
+    if (lane == 63) st_agg(out + 4 * c, a);
+}
+// top level (at most a few hundred words): one wave walks it in batches of 64 and leaves the state BEFORE every entry
+__global__ __launch_bounds__(64) void desc_scan_top(const unsigned long long *__restrict__ in, uint64_t n, uint32_t K1,
+                                                    unsigned long long *__restrict__ states, const Counts *__restrict__ counts) {
+    const int lane = threadIdx.x;
+    if (scan_off(counts)) return;
+    PairState s{0, 0, 0};
+    for (uint64_t b0 = 0; b0 < n; b0 += 64) {
+        const uint64_t i = b0 + lane;
+        const AggF inc = wave_scan_agg(i < n ? ld_agg(in + 4 * i) : agg_identity(), lane, K1);
+        AggF exc;
+        exc.m_f = shfl_up64(inc.m_f, 1);
+        exc.C = shfl_up64(inc.C, 1);
+        exc.N = shfl_up64(inc.N, 1);
+        const uint32_t f = (uint32_t)__shfl_up((int)(inc.q | (inc.dep ? 256u : 0u) | (inc.pass ? 512u : 0u)), 1);
+        exc.q = f & 63u;
+        exc.dep = (f & 256u) != 0;
+        exc.pass = (f & 512u) != 0;
+        if (lane == 0) exc = agg_identity();
+        const PairState mine = applied(s, exc, K1);
+        if (i < n) {
+            states[3 * i] = mine.G;
+            states[3 * i + 1] = mine.Gmn;
+            states[3 * i + 2] = mine.p;
         }
-    }
-    __syncthreads();
-    PairState s{start[threadIdx.x][0], start[threadIdx.x][1], (uint32_t)start[threadIdx.x][2]};
-    for (uint64_t c = c0; c < c1; c++) {
-        chunk_state[3 * c] = s.G;
-        chunk_state[3 * c + 1] = s.Gmn;
-        chunk_state[3 * c + 2] = s.p;
-        apply(s, ld_agg(chunk_agg + 4 * c), K1);
+        const PairState after = applied(s, inc, K1); // lane 63: the whole batch
+        s.G = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(after.G >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)after.G, 63);
+        s.Gmn = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(after.Gmn >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)after.Gmn, 63);
+        s.p = (uint32_t)__shfl((int)after.p, 63);
     }
 }
-
-__global__ __launch_bounds__(256) void desc_scan_write(const unsigned long long *__restrict__ agg, uint64_t n_tiles, uint32_t K1,
-                                                       const unsigned long long *__restrict__ chunk_state, TileState *__restrict__ state,
-                                                       const Counts *__restrict__ counts) {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t t0 = c * SCAN_CH;
-    if (t0 >= n_tiles || counts->need_legacy || counts->bad_input || counts->pool_overflow) return;
-    PairState s{chunk_state[3 * c], chunk_state[3 * c + 1], (uint32_t)chunk_state[3 * c + 2]};
-    for (int i = 0; i < SCAN_CH && t0 + i < n_tiles; i++) {
-        state[t0 + i].g = ((unsigned long long)s.p << 48) | s.G;
-        state[t0 + i].gmn = s.Gmn;
-        apply(s, agg_unpack(agg[t0 + i]), K1);
-    }
-    if (t0 + SCAN_CH >= n_tiles) { // the totals
-        state[n_tiles].g = s.G;
-        state[n_tiles].gmn = s.Gmn;
+// one wave per 64 entries: from the state before the 64 (chunk_states) to the state before every one of them.  Level 0 writes
+// the TileState records (and the totals behind the last tile), the upper level its 24-byte states.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void desc_scan_expand(const unsigned long long *__restrict__ in, uint64_t n, uint32_t K1,
+                                                        const unsigned long long *__restrict__ chunk_states, unsigned long long *__restrict__ out_states,
+                                                        TileState *__restrict__ out_tiles, const Counts *__restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), i = c * 64 + lane;
+    if (c * 64 >= n || scan_off(counts)) return;
+    const PairState s0{chunk_states[3 * c], chunk_states[3 * c + 1], (uint32_t)chunk_states[3 * c + 2]};
+    const AggF inc = wave_scan_agg(i < n ? ld_level<PACKED>(in, i) : agg_identity(), lane, K1);
+    AggF exc;
+    exc.m_f = shfl_up64(inc.m_f, 1);
+    exc.C = shfl_up64(inc.C, 1);
+    exc.N = shfl_up64(inc.N, 1);
+    const uint32_t f = (uint32_t)__shfl_up((int)(inc.q | (inc.dep ? 256u : 0u) | (inc.pass ? 512u : 0u)), 1);
+    exc.q = f & 63u;
+    exc.dep = (f & 256u) != 0;
+    exc.pass = (f & 512u) != 0;
+    if (lane == 0) exc = agg_identity();
+    const PairState mine = applied(s0, exc, K1);
+    if (i < n) {
+        if constexpr (PACKED) {
+            out_tiles[i].g = ((unsigned long long)mine.p << 48) | mine.G;
+            out_tiles[i].gmn = mine.Gmn;
+            if (i + 1 == n) { // the totals
+                const PairState tot = applied(s0, inc, K1);
+                out_tiles[n].g = tot.G;
+                out_tiles[n].gmn = tot.Gmn;
+            }
+        } else {
+            out_states[3 * i] = mine.G;
+            out_states[3 * i + 1] = mine.Gmn;
+            out_states[3 * i + 2] = mine.p;
+        }
     }
 }
 
@@ -110,46 +151,74 @@ __global__ __launch_bounds__(256) void desc_scan_write(const unsigned long long 
 constexpr int DK_WAVES = 4;
 constexpr int DK_KMAX = 32;
 
-__device__ inline uint32_t dk_incl_scan(uint32_t v, int lane) { // inclusive scan over the wave (shuffles; this kernel is not the hot one)
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_up(v, o);
-        if (lane >= o) v += u;
-    }
-    return v;
+// inclusive scan over the 64 lanes with DPP row shifts / broadcasts (as in the tiled kernel; no LDS round trips)
+__device__ inline uint32_t dk_incl_scan(uint32_t v) {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    uint32_t a = v + t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    a += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false); // row_shr:3
+    a += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x114, 0xf, 0xe, false); // row_shr:4, banks 1-3
+    a += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x118, 0xf, 0xc, false); // row_shr:8, banks 2-3
+    a += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+    a += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
+    a += t;
+    return a;
 }
+__device__ inline uint32_t dk_lane(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 
-__global__ __launch_bounds__(64 * DK_WAVES, 4) void desc_kminmer_kernel(uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts) {
+// KT: compile-time k (the window loop is unrolled and reads the ring at constant offsets), or 0: run-time k <= 32
+template <int KT>
+__global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts) {
     __shared__ unsigned long long s_ring[DK_WAVES][64 + DK_KMAX];
     __shared__ unsigned long long s_rs[DK_WAVES][META_SEGS];
     __shared__ int32_t s_adj[DK_WAVES][META_SEGS];
     __shared__ uint32_t s_segb[DK_WAVES][META_SEGS];
     __shared__ uint32_t s_jcar[DK_WAVES][DK_KMAX];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ uint32_t s_cum[DK_WAVES][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: per-tile values are scalar
     const uint64_t t = (uint64_t)blockIdx.x * DK_WAVES + w;
     if (t >= n_tiles) return; // whole waves leave together; no block-level barrier below
-    if (counts->need_legacy || counts->bad_input || counts->pool_overflow) return;
-    const uint32_t k = dz.k, K1 = k - 1;
-    const AggF ag = agg_unpack(dz.agg[t]);
-    const uint32_t N = (uint32_t)ag.N;
+    // ---- round trip 1: everything whose address depends on nothing loaded -- the words of this tile and of the 63 before it,
+    //      its state, its segment list, and its first 64 records under the assumption that they sit in the tile's own slab
+    const uint32_t off_flags = counts->need_legacy | counts->bad_input | counts->pool_overflow;
+    const unsigned long long agw = t >= (uint64_t)lane ? dz.agg[t - lane] : 0ull; // lane 0: this tile; lane i: tile t - i
     const TileState st = dz.state[t];
-    const uint64_t G = st.g & M48, Gmn = st.gmn;
-    const uint32_t p_in = ag.dep ? (uint32_t)(st.g >> 48) & 63u : 0u;
     const TileMeta *m = &dz.meta[t];
     const uint64_t base = m->rec_base, rs0 = m->rs0, t0 = t * (uint64_t)TILE_BASES;
     const uint32_t r0 = m->r0, nb = m->nb, nrd = m->nrd;
+    const uint32_t segstart_raw = lane < META_SEGS ? m->segstart[lane] : 0u, rs16 = lane < META_SEGS ? m->rs16[lane] : 0u;
+    const uint64_t slab = t * rec.slab_cap;
+    uint32_t nh32 = rec.hash[slab + lane], npos = rec.j[slab + lane]; // (slab_cap >= 64: always inside the pool)
+    if (off_flags) return;
+    constexpr bool KFIX = KT > 0;
+    const uint32_t k = KFIX ? (uint32_t)KT : dz.k, K1 = k - 1;
+    const unsigned long long ag0 = ((unsigned long long)dk_lane((uint32_t)(agw >> 32), 0) << 32) | dk_lane((uint32_t)agw, 0);
+    const AggF ag = agg_unpack(ag0);
+    const uint32_t N = (uint32_t)ag.N;
+    const uint64_t G = st.g & M48, Gmn = st.gmn;
+    const uint32_t p_in = ag.dep ? (uint32_t)(st.g >> 48) & 63u : 0u;
+    if (base != slab && (uint32_t)lane < N) { // (rare: the records are in the overflow region, not where they were fetched from)
+        nh32 = rec.hash[base + lane];
+        npos = rec.j[base + lane];
+    }
     // read segments: hits before segment s, where its read starts, and what turns a hit index into an output offset
-    uint32_t segstart = 0;
-    if ((uint32_t)lane <= nb) segstart = m->segstart[lane];
-    const uint32_t nextstart = __shfl_down(segstart, 1);
+    const uint32_t segstart = (uint32_t)lane <= nb ? segstart_raw : 0u;
+    const uint32_t nextstart = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, (int)segstart);
     const uint32_t mine = (uint32_t)lane <= nb ? ((uint32_t)lane < nb ? nextstart : N) - segstart : 0u;
     const uint32_t skip = lane == 0 ? (ag.dep ? K1 - p_in : K1) : K1; // minimizers of a segment that end no k-min-mer
     const uint32_t wseg = (uint32_t)lane <= nb && mine > skip ? mine - skip : 0u;
-    const uint32_t winc = dk_incl_scan(wseg, lane);
-    const uint32_t Wb = winc - wseg, Wt = __shfl(winc, 63);
+    const uint32_t winc = dk_incl_scan(wseg);
+    const uint32_t Wb = winc - wseg, Wt = dk_lane(winc, 63);
     if ((uint32_t)lane <= nb) {
         s_segb[w][lane] = segstart;
         s_adj[w][lane] = (int32_t)Wb - (int32_t)segstart - (int32_t)skip;
-        s_rs[w][lane] = lane ? t0 + m->rs16[lane] : rs0;
+        s_rs[w][lane] = lane ? t0 + rs16 : rs0;
     }
     // km_off / mn_off of the reads that start in (t0, end of the tile]: the first nb inside, the rest exactly at the end
     if (lane >= 1 && (uint32_t)lane <= nrd) {
@@ -166,40 +235,57 @@ __global__ __launch_bounds__(64 * DK_WAVES, 4) void desc_kminmer_kernel(uint64_t
         if (dz.mn_capacity) dz.o_mn_off[n_reads] = Gmn + N;
     }
     if (N == 0) return;
-    // the up to k-1 minimizers of the continuing read that lie before the tile (lane q: the (q+1)-th counted backwards): the last
-    // records of the tiles before this one -- a tile that is one stretch of the read hands on to the tile before it
-    if ((uint32_t)lane < p_in) {
-        uint32_t rem = (uint32_t)lane;
-        uint64_t u = t;
-        uint32_t idx = 0;
-        bool found = false;
-        while (u > 0) {
-            u--;
-            const uint32_t Nu = (uint32_t)((dz.agg[u] >> 28) & 0x3FFFu);
-            if (rem < Nu) {
-                idx = Nu - 1 - rem;
+    // ---- round trip 2: the up to k-1 minimizers of the continuing read that lie before the tile (lane q: the (q+1)-th counted
+    //      backwards) = the last records of the tiles before this one; a tile that is one stretch of the read hands on to the tile
+    //      before it.  The counts of the 63 tiles before this one are in the lanes already.
+    if (p_in) { // wave-uniform
+        const uint32_t Nl = lane >= 1 ? (uint32_t)((agw >> 28) & 0x3FFFu) : 0u; // lane i >= 1: minimizers of tile t - i
+        s_cum[w][lane] = dk_incl_scan(Nl);                                        // ... of tiles t-1 .. t-i together
+        wave_sync();
+        if ((uint32_t)lane < p_in) {
+            const uint32_t q = (uint32_t)lane;
+            int ti = 1;
+            while (ti < 64 && s_cum[w][ti] <= q) ti++; // first tile back whose cumulative count exceeds q
+            uint64_t u = 0;
+            uint32_t idx = 0, Nu = 0;
+            bool found = false;
+            if (ti < 64 && (uint64_t)ti <= t) {
+                u = t - ti;
+                Nu = s_cum[w][ti] - s_cum[w][ti - 1];
+                idx = Nu - 1 - (q - s_cum[w][ti - 1]);
                 found = true;
-                break;
+            } else { // more than 63 tiles back (very sparse minimizers): walk
+                uint32_t rem = q - s_cum[w][63];
+                u = t >= 63 ? t - 63 : 0;
+                while (u > 0) {
+                    u--;
+                    Nu = (uint32_t)((dz.agg[u] >> 28) & 0x3FFFu);
+                    if (rem < Nu) {
+                        idx = Nu - 1 - rem;
+                        found = true;
+                        break;
+                    }
+                    rem -= Nu;
+                }
             }
-            rem -= Nu;
+            if (found) { // (always: p counted these minimizers)
+                const uint64_t bu = Nu <= rec.slab_cap ? u * rec.slab_cap : dz.meta[u].rec_base;
+                const uint32_t pos = rec.j[bu + idx];
+                s_ring[w][K1 - 1 - q] = mix32(rec.hash[bu + idx]);
+                s_jcar[w][K1 - 1 - q] = (uint32_t)(u * (uint64_t)TILE_BASES + (pos & 0x3FFFu) - rs0); // the same read: it starts at rs0
+            }
         }
-        if (found) { // (always: p counted these minimizers)
-            const uint64_t bu = dz.meta[u].rec_base;
-            const uint32_t pos = rec.j[bu + idx];
-            s_ring[w][K1 - 1 - lane] = mix32(rec.hash[bu + idx]);
-            s_jcar[w][K1 - 1 - lane] = (uint32_t)(u * (uint64_t)TILE_BASES + (pos & 0x3FFFu) - rs0); // the same read: it starts at rs0
-        }
+        wave_sync();
     }
-    wave_sync();
-    uint32_t jprev = (uint32_t)lane >= 64u - K1 ? s_jcar[w][lane - (64u - K1)] : 0u; // "the round before the first": the k-1 minimizers before the tile
+    uint32_t jprev = p_in && (uint32_t)lane >= 64u - K1 ? s_jcar[w][lane - (64u - K1)] : 0u; // "the round before the first": the k-1 minimizers before the tile
     uint64_t xacc = 0;
     for (uint32_t i0 = 0; i0 < N; i0 += 64) {
         const uint32_t i = i0 + lane;
         const bool act = i < N;
-        uint32_t h32 = 0, pos = 0;
-        if (act) {
-            h32 = rec.hash[base + i];
-            pos = rec.j[base + i];
+        const uint32_t h32 = nh32, pos = npos;
+        if (i0 + 64 < N && i + 64 < N) { // the next round's records, in flight while this one is worked on
+            nh32 = rec.hash[base + i + 64];
+            npos = rec.j[base + i + 64];
         }
         uint32_t c = 0;
         for (uint32_t s = 1; s <= nb; s++) c += (s_segb[w][s] <= i); // wave-uniform trip count, LDS broadcast
@@ -213,15 +299,29 @@ __global__ __launch_bounds__(64 * DK_WAVES, 4) void desc_kminmer_kernel(uint64_t
         // rank of the hit inside its read, capped: the window that ENDS here exists iff k-1 minimizers of the read precede it
         const uint32_t before = (c == 0 ? p_in : 0u) + (i - s_segb[w][c]);
         const bool win = act && before >= K1;
-        uint64_t f = 0, r = 0;
-        for (uint32_t mm = 0; mm < k; mm++) { // ring[lane + mm] = hit i - (k-1) + mm
+        // F = XOR rotl(x_m, k-1-m), Rv = XOR rotl(x_m, m) over the window (src/lib.rs:238-249, closed form :275-288), by Horner
+        // with rotations by one: f <- rotl(f, 1) ^ x_m;  r <- rotr(r, 1) ^ x_m, Rv = rotl(r, k-1).  ring[lane + m] = hit i - (k-1) + m
+        uint32_t fl = 0, fh = 0, rl = 0, rh = 0;
+        auto step = [&](uint32_t mm) {
             const uint64_t xw = s_ring[w][lane + mm];
-            f = ((f << 1) | (f >> 63)) ^ xw; // F  = XOR rotl(x_m, k-1-m)   (src/lib.rs:238-249, closed form :275-288)
-            r = ((r >> 1) | (r << 63)) ^ xw; // Rv = rotl(XOR rotr(x_m, k-1-m), k-1) = XOR rotl(x_m, m)
+            const uint32_t xl = (uint32_t)xw, xh = (uint32_t)(xw >> 32);
+            const uint32_t nfh = __builtin_amdgcn_alignbit(fh, fl, 31), nfl = __builtin_amdgcn_alignbit(fl, fh, 31);
+            const uint32_t nrl = __builtin_amdgcn_alignbit(rh, rl, 1), nrh = __builtin_amdgcn_alignbit(rl, rh, 1);
+            fl = nfl ^ xl;
+            fh = nfh ^ xh;
+            rl = nrl ^ xl;
+            rh = nrh ^ xh;
+        };
+        if constexpr (KFIX) {
+#pragma unroll
+            for (uint32_t mm = 0; mm < (uint32_t)KT; mm++) step(mm);
+        } else {
+            for (uint32_t mm = 0; mm < k; mm++) step(mm);
         }
-        const uint64_t rvv = rotl64(r, K1);
+        const uint64_t f = ((uint64_t)fh << 32) | fl, rvv = rotl64(((uint64_t)rh << 32) | rl, K1);
         // start = j of the window's first minimizer: k-1 hits back, in this round or the one before it
-        const uint32_t jsame = (uint32_t)__shfl((int)j, (lane - (int)K1) & 63), jbefore = (uint32_t)__shfl((int)jprev, (lane - (int)K1) & 63);
+        const int src = ((lane - (int)K1) & 63) << 2;
+        const uint32_t jsame = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)j), jbefore = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)jprev);
         const uint32_t jstart = (uint32_t)lane >= K1 ? jsame : jbefore;
         const uint64_t hmin = f < rvv ? f : rvv;
         if (win) {
@@ -252,25 +352,35 @@ __global__ __launch_bounds__(64 * DK_WAVES, 4) void desc_kminmer_kernel(uint64_t
 
 } // namespace
 
-size_t desc_scan_tmp_words(uint64_t n_tiles) { return 7 * ((n_tiles + SCAN_CH - 1) / SCAN_CH) + 8; }
+// scan_tmp: level-1 words (4 per 64 tiles) + states (3 each), level-2 words (4 per 4096 tiles) + states (3 each)
+size_t desc_scan_tmp_words(uint64_t n_tiles) {
+    const uint64_t n1 = (n_tiles + 63) / 64, n2 = (n1 + 63) / 64;
+    return 7 * n1 + 7 * n2 + 16;
+}
 
 hipError_t launch_desc_scan(uint64_t n_tiles, Desc dz, unsigned long long *scan_tmp, const Counts *counts, hipStream_t st) {
     if (n_tiles == 0) return hipSuccess;
-    const uint64_t n_chunks = (n_tiles + SCAN_CH - 1) / SCAN_CH;
-    unsigned long long *chunk_agg = scan_tmp, *chunk_state = scan_tmp + 4 * n_chunks;
+    const uint64_t n1 = (n_tiles + 63) / 64, n2 = (n1 + 63) / 64;
+    unsigned long long *w1 = scan_tmp, *s1 = w1 + 4 * n1, *w2 = s1 + 3 * n1, *s2 = w2 + 4 * n2;
     const uint32_t K1 = dz.k - 1;
-    const unsigned blocks = (unsigned)((n_chunks + 255) / 256);
-    hipLaunchKernelGGL(desc_scan_chunks, dim3(blocks), dim3(256), 0, st, dz.agg, n_tiles, K1, chunk_agg, counts);
-    hipLaunchKernelGGL(desc_scan_top, dim3(1), dim3(SCAN_TOP), 0, st, chunk_agg, n_chunks, K1, chunk_state, counts);
-    hipLaunchKernelGGL(desc_scan_write, dim3(blocks), dim3(256), 0, st, dz.agg, n_tiles, K1, chunk_state, dz.state, counts);
+    hipLaunchKernelGGL(desc_scan_reduce<true>, dim3((unsigned)((n1 + 3) / 4)), dim3(256), 0, st, dz.agg, n_tiles, K1, w1, counts);
+    hipLaunchKernelGGL(desc_scan_reduce<false>, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, st, w1, n1, K1, w2, counts);
+    hipLaunchKernelGGL(desc_scan_top, dim3(1), dim3(64), 0, st, w2, n2, K1, s2, counts);
+    hipLaunchKernelGGL(desc_scan_expand<false>, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, st, w1, n1, K1, s2, s1, (TileState *)nullptr, counts);
+    hipLaunchKernelGGL(desc_scan_expand<true>, dim3((unsigned)((n1 + 3) / 4)), dim3(256), 0, st, dz.agg, n_tiles, K1, s1, (unsigned long long *)nullptr,
+                       dz.state, counts);
     return hipGetLastError();
 }
 
 hipError_t launch_desc_kminmers(uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts, hipStream_t st) {
     if (n_tiles == 0) return hipSuccess;
-    if (dz.k == 0 || dz.k > (uint32_t)DK_KMAX) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(desc_kminmer_kernel, dim3((unsigned)((n_tiles + DK_WAVES - 1) / DK_WAVES)), dim3(64 * DK_WAVES), 0, st, n_tiles, n_reads, dz,
-                       rec, counts);
+    if (dz.k == 0 || dz.k > (uint32_t)DK_KMAX || rec.slab_cap < 64) return hipErrorInvalidValue;
+    const dim3 g((unsigned)((n_tiles + DK_WAVES - 1) / DK_WAVES)), b(64 * DK_WAVES);
+    switch (dz.k) { // the benchmark's k and the reference demo's (src/main.rs:13-48) get an unrolled window loop
+    case 10: hipLaunchKernelGGL(desc_kminmer_kernel<10>, g, b, 0, st, n_tiles, n_reads, dz, rec, counts); break;
+    case 5: hipLaunchKernelGGL(desc_kminmer_kernel<5>, g, b, 0, st, n_tiles, n_reads, dz, rec, counts); break;
+    default: hipLaunchKernelGGL(desc_kminmer_kernel<0>, g, b, 0, st, n_tiles, n_reads, dz, rec, counts); break;
+    }
     return hipGetLastError();
 }
 
