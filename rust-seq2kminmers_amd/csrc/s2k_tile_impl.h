@@ -64,7 +64,7 @@ constexpr int TW = S2K_TW;                                 // waves per block = 
                                                        // tables (4 KiB once instead of three times)
 constexpr int HS_OFF = 16;                             // data starts here; byte HS_OFF-1 absorbs "slot -1" stores
 constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window slack
-constexpr int CAPP = 16;                               // positions per capture piece
+constexpr int CAPP = 16;                               // positions per capture piece (8 measured in rounds 2 and 3: half the re-derivations, no gain)
 constexpr int NPC = TILE_T / CAPP;                     // 9 capture pieces per lane
 constexpr int MAX_L_TILED = 64;
 #ifndef S2K_LISTCAP
@@ -1157,9 +1157,9 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     const uint32_t cur_g = (uint32_t)((blockIdx.x * TW + w) % TILE_CURSORS);
     unsigned int *const cursors = (unsigned int *)(pool_cursor + 16); // 32-bit draws (a 64-bit result's dead upper half would be
                                                                        // reused early and pull a vmcnt(0) in front of the compaction); cursor g = word 32 g
-    // (A wave stays with its cursor: when that runs dry the wave is done.  Moving on to another cursor -- round 2 did, for the
-    // last fraction of a percent of balance at the end of the kernel -- could hand a wave a tile BELOW one it already holds, and
-    // the fused path's look-back relies on every wave walking its tiles in increasing order.)
+    // (A wave stays with its cursor: when that runs dry the wave is done.  Round 2 let it move on to another cursor that was not;
+    // measured again in round 3 (same-call A/B, profiles/r03_ab_knobs.txt) that costs 1 % instead of gaining anything: the 64
+    // cursors run dry within a tile time of each other, and the extra code sits in the tile loop.)
     uint32_t r0n = 0, r1n = 0;
     if (tn < n_tiles) {
         r0n = tile_read0[tn];
