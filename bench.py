@@ -55,7 +55,15 @@ def parse_args():
     ap.add_argument("--verify-reads", type=int, default=2000, help="reads drawn across the whole stream and compared field by field with the oracle (outside the timed region)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: map every rank to GPU 0")
-    ap.add_argument("--count", action="store_true", help="also time the downstream k-min-mer count (hash table in HBM; N > 1: all-to-all by hash prefix)")
+    ap.add_argument("--count", choices=["auto", "on", "off"], default="auto", nargs="?", const="on",
+                    help="downstream k-min-mer count (hash table in HBM; N > 1: ONE all-to-all by hash prefix over RCCL), outside the headline. "
+                         "auto = on when N > 1, so that every multi-GPU run exercises the one real exchange step of the path")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank owns its own batch (c2: 10 Gbp each; ont: 1.25 M reads each).  strong: --workload ont with a "
+                         "FIXED total (--total-reads, default 10 M reads = ~200 Gbp = BASELINE configs[2]) cut over the N ranks")
+    ap.add_argument("--total-reads", type=int, default=10_000_000, help="--scaling strong: reads of the whole job")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive legs (host->host s2k_extract, s2k_run_file) that N=1 runs after the timed region")
+    ap.add_argument("--e2e-reads", type=int, default=400_000, help="reads (of --read-len bases) of the PCIe-inclusive legs: 4 Gbp by default")
     ap.add_argument("--legacy-path", action="store_true", help="legacy records (16 B with the read index + per-read scans) instead of the descriptor path")
     ap.add_argument("--dump-shard", default=None, help="(tests) write this rank's outputs to <path>.rank<r>.npz")
     return ap.parse_args()
@@ -141,6 +149,12 @@ def main():
     import torch
     from s2k_loader import import_package
 
+    n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if not args.single_device and n_dev < args.gpus:
+        sys.exit("bench.py: --gpus %d but only %d GPU(s) visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); "
+                 "--single-device maps every rank to GPU 0 for rehearsals" % (args.gpus, n_dev))
+    if args.scaling == "strong" and args.workload != "ont":
+        sys.exit("bench.py: --scaling strong is defined for --workload ont (BASELINE configs[2]: one 200 Gbp batch cut over the GPUs)")
     pkg = import_package()
     dist = None
     if world > 1:
@@ -157,6 +171,20 @@ def main():
     dev = torch.device("cuda", local_rank)
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the few collective words live
     torch.cuda.set_device(dev)
+    collective = None
+    if dist is not None:
+        # proof that the process group really spans N ranks on N devices: every rank contributes (rank, device index, PCI bus id)
+        props = torch.cuda.get_device_properties(dev)
+        me = torch.tensor([rank, local_rank, hash(getattr(props, "pci_bus_id", local_rank)) & 0x7FFFFFFF], dtype=torch.int64, device=red_dev)
+        allv = [torch.zeros_like(me) for _ in range(dist.get_world_size())]
+        dist.all_gather(allv, me)
+        collective = {"backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "world_size_seen": dist.get_world_size(),
+                      "ranks": [int(v[0]) for v in allv], "devices": [int(v[1]) for v in allv],
+                      "distinct_devices": len({(int(v[1]), int(v[2])) for v in allv}), "visible_devices": n_dev,
+                      "device_name": props.name}
+        assert collective["world_size_seen"] == args.gpus and sorted(collective["ranks"]) == list(range(args.gpus)), collective
+        if not args.single_device:
+            assert collective["distinct_devices"] == args.gpus, "ranks share a device: %r" % (collective,)
     eng = pkg.Engine(local_rank)
     stream = torch.cuda.current_stream(dev)
     eng.set_stream(stream.cuda_stream)  # one stream for torch events and the library's kernels
@@ -182,7 +210,15 @@ def main():
         wl_text = "%d x %d bp uniform-random ACGT reads per GPU (%.1f Gbp/GPU)" % (n_reads, rl, n_bases / 1e9)
     else:
         per_gpu = args.reads or 1_250_000
-        lens = ont_lengths(per_gpu * world)
+        total_reads = args.total_reads if args.scaling == "strong" else per_gpu * world
+        if args.scaling == "strong": # the whole job is fixed; refuse what cannot fit one rank's HBM instead of dying in an allocation
+            est = total_reads * 20000 // world
+            need = est * (1.0 + 2.4 * args.density * 17 + 2.1 * args.density * 8) + (4 << 30)
+            free_b, total_b = torch.cuda.mem_get_info(dev)
+            if need > free_b:
+                sys.exit("bench.py: --scaling strong: %.0f Gbp per rank needs ~%.0f GB of HBM, %.0f GB free: use more GPUs or --total-reads (%d reads fit)"
+                         % (est / 1e9, need / 1e9, free_b / 1e9, int(total_reads * (free_b * 0.9) / need)))
+        lens = ont_lengths(total_reads)
         goff = np.zeros(len(lens) + 1, dtype=np.uint64)
         np.cumsum(lens, out=goff[1:])
         b = sharding.shard_bounds(goff, world)
@@ -192,8 +228,8 @@ def main():
         d_off = torch.from_numpy(host_off.astype(np.int64)).to(dev)
         shard_info = {"reads_total": int(len(lens)), "bases_total": int(goff[-1]), "reads_this_rank": n_reads, "bases_this_rank": n_bases,
                       "sharding": "contiguous read ranges balanced by cumulative bases (sharding.shard_bounds)"}
-        wl_text = "%d ragged reads, lognormal(mean 20 kbp, sigma 0.5) clipped [1k,200k] (%.1f Gbp) in %d shard(s)" % (
-            len(lens), int(goff[-1]) / 1e9, world)
+        wl_text = "%d ragged reads, lognormal(mean 20 kbp, sigma 0.5) clipped [1k,200k] (%.1f Gbp) in %d shard(s), %s scaling" % (
+            len(lens), int(goff[-1]) / 1e9, world, args.scaling)
     d_bases = torch.empty(n_bases + 256, dtype=torch.uint8, device=dev)
     eng.synth_bases_device(seed, first_base, n_bases, d_bases.data_ptr())
     cap = int(n_bases * (2.4 * args.density)) + 1_000_000
@@ -231,13 +267,16 @@ def main():
         all_ms, _ = eng.timing_total(0)
         eng.enable_timing(False)
         assert k_n == steps, "internal re-runs (workspace growth) inside the timed region: %d event sets for %d steps" % (k_n, steps)
+        spread = None
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            t = torch.tensor([dt, -dt, all_ms / steps, -(all_ms / steps)], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, counts, k_ms / steps, km_ms / steps, all_ms / steps
+            dt = float(t[0].item())
+            spread = {"wall_ms_per_step_max": round(float(t[0].item()) / steps * 1e3, 3), "wall_ms_per_step_min": round(-float(t[1].item()) / steps * 1e3, 3),
+                      "kernels_ms_per_step_max": round(float(t[2].item()), 3), "kernels_ms_per_step_min": round(-float(t[3].item()), 3)}
+        return dt, counts, k_ms / steps, km_ms / steps, all_ms / steps, spread
 
-    dt, counts, min_ms, km_ms, pipe_ms = timed(mode, args.steps, args.warmup)
+    dt, counts, min_ms, km_ms, pipe_ms, rank_spread = timed(mode, args.steps, args.warmup)
     assert counts["path"] == (2 if args.legacy_path else 0), "the tiled HIP kernels (descriptor path unless --legacy-path) must be the ones measured"
     # ---- verification outside the timed region: a read sample against the oracle ------------------
     verified = None
@@ -282,7 +321,7 @@ def main():
     other_line = None
     if not args.no_other_mode:
         s2 = max(2, args.steps // 2)
-        dt2, counts2, min_ms2, km_ms2, pipe_ms2 = timed(other, s2, 1)
+        dt2, counts2, min_ms2, km_ms2, pipe_ms2, _ = timed(other, s2, 1)
         alg2 = counts2["n_bases"] + 17 * counts2["n_kminmers"] + 16 * (n_reads + 1)
         tot2 = sharding.allreduce_counts(counts2, dist, red_dev)
         other_line = {"mode": "regular" if args.mode == "hpc" else "hpc", "value": round(tot2["n_bases"] * s2 / dt2 / 1e9, 2), "unit": "Gbp/s",
@@ -301,7 +340,7 @@ def main():
 
     # ---- downstream of the path, outside the headline: distinct k-min-mer hashes over all ranks -------------
     count_line = None
-    if args.count:
+    if args.count == "on" or (args.count == "auto" and world > 1):
         ops = sharding.EngineCountOps(eng, dev)
         keys = outs["hash"][: counts["n_kminmers"]]
         sharding.count_kminmers(keys, ops, dist, collectives_on_device=(args.backend == "nccl"))  # warm-up (table allocation)
@@ -351,6 +390,56 @@ def main():
                 "kernel_ms": round(min_ms, 3), "kernel_bytes": int(kern_bytes),
                 "kernel_frac": round(kern_bytes / (min_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kminmer_kernel_ms": round(km_ms, 3),
                 "limiter": "integer VALU issue, not HBM: see DESIGN.md 3.1 and tools/experiments/valu_rate.hip"}
+
+    # ---- PCIe-inclusive legs (SURVEY 8d "what is timed (2)"): never `value`, reported beside it; N = 1, outside the timed region -----
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_end_to_end and args.workload == "c2":
+        import ctypes as C
+
+        ne = min(args.e2e_reads, n_reads)
+        rl = args.read_len
+        hb = d_bases[: ne * rl].cpu().numpy()  # pageable host memory, as a caller's buffer would be
+        hoff = np.arange(ne + 1, dtype=np.uint64) * rl
+
+        def c_extract(m):  # the C call alone (what a Rust / C++ caller pays): host buffers in, host SoA out
+            p = pkg.Params(args.l, args.k, args.density, int(m), 0)
+            res = pkg.Result()
+            t0 = time.perf_counter()
+            st = eng.lib.s2k_extract(eng.ctx, hb.ctypes.data_as(C.c_void_p), hoff.ctypes.data_as(C.c_void_p), ne, C.byref(p), C.byref(res))
+            dt = time.perf_counter() - t0
+            assert st == 0, st
+            nk = int(res.n_kminmers)
+            eng.lib.s2k_result_free(C.byref(res))
+            return dt, nk
+
+        legs = {}
+        for m, name in ((mode, args.mode), (other, "regular" if args.mode == "hpc" else "hpc")):
+            c_extract(m)  # warm-up: pinned rings, result pool
+            dt_e, nk_e = min(c_extract(m) for _ in range(3))
+            legs[name] = {"gbp_s": round(ne * rl / dt_e / 1e9, 2), "ms": round(dt_e * 1e3, 2), "kminmers": nk_e,
+                          "bytes_over_link": {"h2d": int(ne * rl // 4 + 8 * (ne + 1)), "d2h": int(17 * nk_e + 8 * (ne + 1)),
+                                              "note": "bases travel 2-bit packed (4 per byte; every byte that is not A/C/G/T in an exception list), results as SoA"}}
+        file_leg = None
+        try:
+            path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "s2k_bench_%d.fa" % os.getpid())
+            with open(path, "wb") as f:
+                for i in range(ne):
+                    f.write(b">r%d\n" % i)
+                    f.write(hb[i * rl:(i + 1) * rl].tobytes())
+                    f.write(b"\n")
+            fbytes = os.path.getsize(path)
+            eng.run_file(path, args.l, args.k, args.density, mode)  # warm-up: page cache settles
+            best = min((eng.run_file(path, args.l, args.k, args.density, mode) for _ in range(2)), key=lambda r: r["seconds"])
+            file_leg = {"gbp_s": round(best["n_bases"] / best["seconds"] / 1e9, 2), "ms": round(best["seconds"] * 1e3, 2), "file_bytes": int(fbytes),
+                        "what": "s2k_run_file on a FASTA of the same reads in the page cache: read, staged 2-bit packed, split into records on the GPU, "
+                                "k-min-mers counted as in src/main.rs:65-81 (wall clock of the whole call)"}
+            os.remove(path)
+        except OSError as ex:  # no room for the file: the leg is skipped, the bench line stands
+            file_leg = "n/a (%s)" % type(ex).__name__
+        e2e = {"what": "s2k_extract: %d reads x %d bp (%.1f Gbp) in pageable host memory -> k-min-mers in host SoA, best of 3 after a warm-up" % (ne, rl, ne * rl / 1e9),
+               "gbp_s": legs[args.mode]["gbp_s"], "bytes_over_link": legs[args.mode]["bytes_over_link"], "host_cpus": usable_cpus(),
+               "modes": legs, "run_file": file_leg}
+        del hb
 
     # ---- CPU baseline: the oracle = scalar port of the reference, on this host's cores --------------
     cpu = None
@@ -405,7 +494,7 @@ def main():
         line = {
             "metric": "input bases/s (Gbp/s) for k-min-mer extraction, l=%d k=%d d=%g" % (args.l, args.k, args.density),
             "value": round(value, 2), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": dict({"workload": "%s, HashMode::%s, l=%d k=%d d=%g; inputs resident in HBM" % (
                 wl_text, "Hpc" if mode == pkg.HashMode.Hpc else "Regular", args.l, args.k, args.density),
@@ -413,7 +502,8 @@ def main():
                 "largest_shard_over_mean": balance}, **shard_info),
             "counts": {"bases": tot_bases, "minimizers": tot_min, "kminmers": tot_km, "xor_hash_rank0": counts["xor_hash"]},
             "verified_vs_oracle": verified,
-            "other_mode": other_line, "downstream_count": count_line,
+            "other_mode": other_line, "downstream_count": count_line, "collective": collective, "per_rank": rank_spread,
+            "end_to_end": e2e,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

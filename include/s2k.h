@@ -33,7 +33,8 @@ extern "C" {
 /* ABI history.  1: round-1 surface.  2: + s2k_set_host_batch, s2k_hpc_device_ex, s2k_count_device, s2k_partition_device,
  * S2K_FLAG_NO_PACK2; s2k_extract sends 2-bit packed bases and pipelines sub-batches by default; the arrays of an s2k_result
  * are NULL when their count is 0; device-resident read tables are validated on the device (S2K_ERR_INVALID_ARG /
- * S2K_ERR_READ_TOO_LONG from s2k_extract_device, s2k_sync and s2k_hpc_device*); S2K_ERR_NON_ASCII is no longer returned.
+ * S2K_ERR_READ_TOO_LONG from s2k_extract_device, s2k_sync and s2k_hpc_device*); S2K_ERR_NON_ASCII is no longer returned;
+ * + s2k_trim, s2k_density_for_bound, S2K_FLAG_LEGACY_PATH; s2k_counts.path tells the descriptor path (0) from the legacy one (2).
  * A binding must refuse a library whose s2k_abi_version() differs from the header it was built against. */
 #define S2K_ABI_VERSION 2
 
@@ -139,6 +140,10 @@ const char *s2k_last_error(const s2k_ctx *ctx);
 
 /* (density * u32::MAX as f64) as u32 -- src/lib.rs:91 */
 uint32_t s2k_hash_bound(double density);
+/* A density d with s2k_hash_bound(d) == bound, for callers that hold the u32 bound itself -- the crate's minimizer iterators
+ * take it instead of a density: NtHashHPCIterator::new(seq, k, hash_bound) src/nthash_hpc.rs:115, NtHashSIMDIterator::new
+ * src/nthash_avx512_32.rs:32, NtHashHPCSIMDIterator::new src/nthash_hpc_simd.rs:35. */
+double s2k_density_for_bound(uint32_t bound);
 
 /* ---- the hot path ---------------------------------------------------------------------------- */
 /* Replaces: for each read r { KminmersIterator::new(&bases[read_off[r]..read_off[r+1]], l, k, density,

@@ -3,6 +3,7 @@
 //   range-for over it yields s2k::KminmerHash           ~  impl Iterator             src/lib.rs:179-270
 //   s2k::KminmerHash{hash,start,end,offset,rev}, == / < by hash only               src/kminmer.rs:128-135,181-204
 //   s2k::HashMode                                                                    src/lib.rs:21-27
+//   s2k::NtHashHPCIterator / NtHashSIMDIterator / NtHashHPCSIMDIterator (seq, l, hash_bound)   src/lib.rs:6-13 (re-exports)
 // Parameter violations that panic in the reference throw s2k::Error here.  The efficient entry point is
 // Engine::extract (a batch of reads per call); the per-read iterator exists for reference-style call sites.
 #pragma once
@@ -55,6 +56,7 @@ class Batch { // owns one s2k_result
         uint64_t g = res_.km_off[r] + i;
         return KminmerHash{res_.hash[g], res_.start[g], res_.end[g], (size_t)i, res_.rev[g] != 0};
     }
+    uint64_t n_minimizers() const { return res_.n_minimizers; } // with S2K_FLAG_WANT_MINIMIZERS
     const s2k_result &raw() const { return res_; }
     s2k_result *out() { return &res_; }
 
@@ -86,14 +88,14 @@ class Engine { // one per thread and device (like one KminmersIterator per threa
         if (st != S2K_OK) throw Error(st, std::string(s2k_strerror(st)) + ": " + s2k_last_error(ctx_));
         return b;
     }
-    Batch extract(const std::vector<std::string_view> &reads, size_t l, size_t k, double density, HashMode mode) {
+    Batch extract(const std::vector<std::string_view> &reads, size_t l, size_t k, double density, HashMode mode, uint32_t flags = 0) {
         std::vector<uint64_t> off(reads.size() + 1, 0);
         std::string bases;
         for (size_t i = 0; i < reads.size(); i++) {
             bases.append(reads[i]);
             off[i + 1] = bases.size();
         }
-        return extract(reinterpret_cast<const uint8_t *>(bases.data()), off.data(), reads.size(), l, k, density, mode);
+        return extract(reinterpret_cast<const uint8_t *>(bases.data()), off.data(), reads.size(), l, k, density, mode, flags);
     }
     s2k_ctx *raw() { return ctx_; }
 
@@ -122,6 +124,43 @@ class KminmersIterator { // src/lib.rs:70-131: per-read facade
   private:
     Batch batch_;
 };
+
+// The crate's minimizer iterators (re-exported at src/lib.rs:6-13), over S2K_FLAG_WANT_MINIMIZERS.  Like the reference they take
+// the u32 hash bound, not a density.  One GPU call per sequence: for throughput use Engine::extract with the flag on a batch.
+// Defined for seq.size() > l, the only way KminmersIterator constructs them (src/lib.rs:97-109); l > seq.size() throws as
+// KSizeOutOfRange does (src/nthash_hpc.rs:117-121).
+struct Minimizer { // NtHashHPCIterator::Item = (start, end, hash), src/nthash_hpc.rs:193
+    size_t start, end;
+    uint32_t hash;
+};
+template <HashMode MODE>
+class MinimizerIterator {
+  public:
+    MinimizerIterator(Engine &eng, std::string_view seq, size_t l, uint32_t hash_bound) {
+        if (l > seq.size()) throw Error(S2K_ERR_L_RANGE, "K size is out of range for the given sequence size"); // src/nthash_hpc.rs:19-22
+        if (seq.size() == l) throw Error(S2K_ERR_INVALID_ARG, "the minimizer iterators are reproduced for seq.len() > l (src/lib.rs:97)");
+        batch_ = eng.extract(std::vector<std::string_view>{seq}, l, 1, s2k_density_for_bound(hash_bound), MODE, S2K_FLAG_WANT_MINIMIZERS);
+    }
+    struct iterator {
+        const s2k_result *r;
+        uint64_t i;
+        Minimizer operator*() const { return Minimizer{r->mn_j[i], r->mn_jend[i], r->mn_hash[i]}; }
+        iterator &operator++() {
+            ++i;
+            return *this;
+        }
+        bool operator!=(const iterator &o) const { return i != o.i; }
+    };
+    iterator begin() const { return iterator{&batch_.raw(), 0}; }
+    iterator end() const { return iterator{&batch_.raw(), batch_.n_minimizers()}; }
+    size_t size() const { return (size_t)batch_.n_minimizers(); }
+
+  private:
+    Batch batch_;
+};
+using NtHashHPCIterator = MinimizerIterator<HashMode::Hpc>;         // src/nthash_hpc.rs:99-283: `<=`, last HPC l-mer dropped, end = last base of the last run
+using NtHashHPCSIMDIterator = MinimizerIterator<HashMode::HpcSimd>; // src/nthash_hpc_simd.rs:17-68: `<` vs f32 bound, end = start of the last run
+using NtHashSIMDIterator = MinimizerIterator<HashMode::Simd>;       // src/nthash_avx512_32.rs:14-164: Item = (pos, hash): use .start and .hash
 
 inline uint32_t hash_bound(double density) { return s2k_hash_bound(density); } // src/lib.rs:91
 

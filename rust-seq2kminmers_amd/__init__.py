@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libs2k.so")
 ABI_VERSION = 2  # include/s2k.h S2K_ABI_VERSION this mirror was written against
 
 ABI_SYMBOLS = [
-    "s2k_trim", "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_set_host_batch", "s2k_strerror",
+    "s2k_trim", "s2k_density_for_bound", "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_set_host_batch", "s2k_strerror",
     "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
     "s2k_hpc_device", "s2k_hpc_device_ex", "s2k_count_device", "s2k_partition_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
 ]
@@ -114,6 +114,8 @@ def load_library(path=None):
     L.s2k_last_error.argtypes = [C.c_void_p]
     L.s2k_hash_bound.restype = C.c_uint32
     L.s2k_hash_bound.argtypes = [C.c_double]
+    L.s2k_density_for_bound.restype = C.c_double
+    L.s2k_density_for_bound.argtypes = [C.c_uint32]
     L.s2k_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Params), C.POINTER(Result)]
     L.s2k_result_free.argtypes = [C.POINTER(Result)]
     L.s2k_result_free.restype = None
@@ -418,6 +420,74 @@ class KminmersIterator:
         self._i += 1
         r = self._r
         return KminmerHash(int(r["hash"][i]), int(r["start"][i]), int(r["end"][i]), i, bool(r["rev"][i]))
+
+
+class _MinimizerTriples:
+    """The crate's minimizer iterators (re-exported at src/lib.rs:6-13) over S2K_FLAG_WANT_MINIMIZERS: one GPU call per
+    sequence -- the wrong granularity for throughput (use Engine.extract(..., want_minimizers=True) for batches); these
+    classes exist so reference-style call sites read the same.  Like the reference they take the u32 `hash_bound`, not a
+    density.  Defined for len(seq) > l, the only way KminmersIterator constructs them (src/lib.rs:97-109); l > len(seq)
+    raises as KSizeOutOfRange does (src/nthash_hpc.rs:117-121)."""
+    _mode = None
+
+    def __init__(self, seq, l, hash_bound, engine=None):
+        a = _as_u8(seq)
+        if l > len(a):
+            raise S2kError(2, "K size %d is out of range for the given sequence size %d" % (l, len(a)))  # src/nthash_hpc.rs:19-22
+        if len(a) == l:
+            raise ValueError("the minimizer iterators are reproduced for seq.len() > l (src/lib.rs:97)")
+        eng = engine or default_engine()
+        d = float(eng.lib.s2k_density_for_bound(int(hash_bound)))
+        r = eng.extract_reads([a], l, 1, d, self._mode, want_minimizers=True)
+        assert r["counts"]["hash_bound"] == int(hash_bound)
+        self._j, self._jend, self._h = r["mn_j"], r["mn_jend"], r["mn_hash"]
+        self._i = 0
+
+    @classmethod
+    def new(cls, seq, l, hash_bound, engine=None):
+        return cls(seq, l, hash_bound, engine)
+
+    def __iter__(self):
+        return self
+
+    def __len__(self):
+        return len(self._h) - self._i
+
+    def _item(self, i):
+        return int(self._j[i]), int(self._jend[i]), int(self._h[i])
+
+    def __next__(self):
+        if self._i >= len(self._h):
+            raise StopIteration
+        self._i += 1
+        return self._item(self._i - 1)
+
+
+class NtHashHPCIterator(_MinimizerTriples):
+    """src/nthash_hpc.rs:99-283: Item = (start, end, hash) in original space; `<=` against the bound; the last HPC l-mer of the
+    sequence is never yielded (:265-267); end = last base of the l-mer's last run (:281)."""
+    _mode = HashMode.Hpc
+
+
+class NtHashHPCSIMDIterator(_MinimizerTriples):
+    """src/nthash_hpc_simd.rs:17-68: Item = (start, end, hash); the result semantics of the AVX-512 path: strict `<` against a
+    bound re-derived through f32, end = START of the last run (:64), the last l-mer kept, the final block of 16 lost when the
+    number of l-mers is a multiple of 16."""
+    _mode = HashMode.HpcSimd
+
+
+class NtHashSIMDIterator(_MinimizerTriples):
+    """src/nthash_avx512_32.rs:14-164: Item = (pos, hash) over the sequence as it is (no homopolymer compression)."""
+    _mode = HashMode.Simd
+
+    def _item(self, i):
+        return int(self._j[i]), int(self._h[i])
+
+
+class RegularMinimizers(_MinimizerTriples):
+    """Not a type of the crate: the (j, jend, hash) triples that the Regular arm of KminmersIterator::next makes from the external
+    nthash32::NtHashIterator (src/lib.rs:215-230), for symmetry with the three above."""
+    _mode = HashMode.Regular
 
 
 def _hpc_gpu(seq, engine, rle):

@@ -543,6 +543,12 @@ extern "C" {
 
 int s2k_abi_version(void) { return S2K_ABI_VERSION; }
 
+double s2k_density_for_bound(uint32_t bound) {
+    if (bound == 0xFFFFFFFFu) return 1.0;
+    const double d = ((double)bound + 0.5) / 4294967295.0; // d * u32::MAX lands half way between bound and bound + 1: truncates to bound
+    return hash_bound(d) == bound ? d : ((double)bound + 0.25) / 4294967295.0;
+}
+
 int s2k_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -20,6 +20,12 @@ int main(int argc, char **argv) {
                                  (s2k::HashMode)std::stoi(argv[5]));
         for (s2k::KminmerHash km : it)
             std::printf("%llu %zu %zu %zu %d\n", (unsigned long long)km.get_hash(), km.start, km.end, km.offset, (int)km.rev);
+        if (argc > 6) { // minimizer-triple iterators over the same sequence: "M <mode> start end hash" lines
+            const uint32_t bound = s2k::hash_bound(std::stod(argv[4]));
+            for (s2k::Minimizer m : s2k::NtHashHPCIterator(eng, seq, std::stoul(argv[2]), bound)) std::printf("M 1 %zu %zu %u\n", m.start, m.end, m.hash);
+            for (s2k::Minimizer m : s2k::NtHashSIMDIterator(eng, seq, std::stoul(argv[2]), bound)) std::printf("M 2 %zu %zu %u\n", m.start, m.end, m.hash);
+            for (s2k::Minimizer m : s2k::NtHashHPCSIMDIterator(eng, seq, std::stoul(argv[2]), bound)) std::printf("M 3 %zu %zu %u\n", m.start, m.end, m.hash);
+        }
         // error behaviour: k == 0 panics in the reference (src/lib.rs:246), throws here
         try {
             s2k::KminmersIterator bad(eng, seq, 31, 0, 0.01, s2k::HashMode::Regular);

@@ -35,6 +35,12 @@ def test_two_ranks_equal_unsharded(tmp_path):
     assert one["counts"] == {**two["counts"], "xor_hash_rank0": one["counts"]["xor_hash_rank0"]}  # whole-job totals agree
     assert two["config"]["reads_total"] == 6000 and 1.0 <= two["config"]["largest_shard_over_mean"] < 1.01
     assert one["verified_vs_oracle"] and two["verified_vs_oracle"]
+    # the JSON proves how many ranks the process group saw, and the one real exchange step (count: all-to-all by hash prefix) ran
+    assert one["collective"] is None and two["collective"]["world_size_seen"] == 2 and two["collective"]["ranks"] == [0, 1]
+    assert two["per_rank"]["wall_ms_per_step_max"] >= two["per_rank"]["wall_ms_per_step_min"] > 0
+    assert one["downstream_count"] is None and two["downstream_count"]["n_keys"] == two["counts"]["kminmers"]
+    assert two["downstream_count"]["exchange"].startswith("all_to_all_single")
+    assert one["scaling"] == "weak" and one["end_to_end"] is None  # (ont workload: the PCIe legs belong to the c2 line)
     a = np.load(os.path.join(tmp, "one.rank0.npz"))
     parts = [np.load(os.path.join(tmp, "two.rank%d.npz" % r)) for r in range(2)]
     assert int(parts[0]["first_base"]) == 0 and int(parts[1]["first_base"]) == int(parts[0]["n_bases"])  # contiguous shards of one stream
@@ -42,6 +48,27 @@ def test_two_ranks_equal_unsharded(tmp_path):
         assert (np.concatenate([p[f] for p in parts]) == a[f]).all(), f
     km = np.concatenate([parts[0]["km_off"][:-1], parts[1]["km_off"] + parts[0]["km_off"][-1]])
     assert (km == a["km_off"]).all()
+
+
+@pytest.mark.gpu
+def test_strong_scaling_cuts_one_fixed_batch(tmp_path):
+    tmp = str(tmp_path)
+    one = run_bench(["--gpus", "1", "--scaling", "strong", "--total-reads", "6000"], tmp, "s1")
+    two = run_bench(["--gpus", "2", "--scaling", "strong", "--total-reads", "6000", "--single-device", "--backend", "gloo"], tmp, "s2")
+    assert one["scaling"] == two["scaling"] == "strong"
+    assert one["config"]["reads_total"] == two["config"]["reads_total"] == 6000 and one["counts"]["bases"] == two["counts"]["bases"]
+    assert one["counts"]["kminmers"] == two["counts"]["kminmers"]
+
+
+def test_more_ranks_than_gpus_fails_loudly():
+    """no GPU (or fewer than --gpus) visible: every rank says so and exits non-zero before anything touches a device"""
+    import torch
+
+    n = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 2)], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout)
 
 
 def test_gpus_flag_must_match_world_size():

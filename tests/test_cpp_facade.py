@@ -37,3 +37,12 @@ def test_cpp_facade_matches_oracle(tmp_path, oracle, ecoli):
         ref = oracle.kminmers(ecoli, l, k, d, omode)
         exp = [(int(h), int(s), int(e), i, int(r)) for i, (h, s, e, r) in enumerate(zip(ref["hash"], ref["start"], ref["end"], ref["rev"]))]
         assert got == exp
+    # the minimizer-triple iterators of the facade (NtHashHPCIterator / NtHashSIMDIterator / NtHashHPCSIMDIterator)
+    out = subprocess.run([exe, str(seqf), "21", "4", "0.02", "1", "minimizers"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    rows = [line.split() for line in out.stdout.splitlines() if line.startswith("M ")]
+    bound = oracle.hash_bound(0.02)
+    for mode, omode in ((1, so.HPC), (2, so.SIMD), (3, so.HPCSIMD)):
+        got = [(int(r[2]), int(r[3]), int(r[4])) for r in rows if int(r[1]) == mode]
+        j, je, h = oracle.minimizers(ecoli, 21, bound, omode)
+        assert got == list(zip(map(int, j), map(int, je), map(int, h))) and len(got) > 100, mode

@@ -760,6 +760,33 @@ def test_full_size_config5_whole_run_checksums(eng, oracle):
         assert sample_reads_compare(t, n, oracle, seed, 0, lambda r: (r * L, L), ids, 31, 10, 0.001, OMODE[mode], threads=threads) > 0
 
 
+def test_minimizer_iterator_facades(eng, oracle, ecoli):
+    """The crate's minimizer iterators (re-exported at src/lib.rs:6-13) as Python classes over S2K_FLAG_WANT_MINIMIZERS, against
+    the oracle's minimizers in all four modes: NtHashHPCIterator yields (start, end, hash) (src/nthash_hpc.rs:193),
+    NtHashSIMDIterator (pos, hash) (src/nthash_avx512_32.rs), NtHashHPCSIMDIterator (start, end, hash) (src/nthash_hpc_simd.rs:56-66);
+    they take the u32 hash bound like the reference."""
+    from oracle import s2k_oracle as so
+
+    rng = np.random.default_rng(2024)
+    seqs = [ecoli[:30000], rand_read(rng, 12345, hp=0.3, odd=0.01), rand_read(rng, 48 + 31, hp=0.0), b"ACGT" * 20 + b"A" * 500 + b"CGTA" * 30]
+    for l, d in ((31, 0.01), (12, 0.05), (28, 0.1)):
+        bound = oracle.hash_bound(d)
+        assert pkg.hash_bound(pkg.load_library().s2k_density_for_bound(bound)) == bound
+        for seq in seqs:
+            for cls, omode, pair in ((pkg.NtHashHPCIterator, so.HPC, False), (pkg.NtHashHPCSIMDIterator, so.HPCSIMD, False),
+                                     (pkg.NtHashSIMDIterator, so.SIMD, True), (pkg.RegularMinimizers, so.REGULAR, False)):
+                j, je, h = oracle.minimizers(seq, l, bound, omode)
+                it = cls.new(seq, l, bound, engine=eng)
+                assert len(it) == len(h)
+                got = list(it)
+                exp = list(zip(map(int, j), map(int, h))) if pair else list(zip(map(int, j), map(int, je), map(int, h)))
+                assert got == exp, (cls.__name__, l, d, len(seq))
+    for b in (0, 1, 12345, 0x028F5C28, 0x7FFFFFFF, 0xFFFFFFFE, 0xFFFFFFFF):  # every bound is reachable through a density
+        assert pkg.hash_bound(pkg.load_library().s2k_density_for_bound(b)) == b
+    with pytest.raises(pkg.S2kError):
+        pkg.NtHashHPCIterator(b"ACGT", 31, 1000, engine=eng)  # KSizeOutOfRange, src/nthash_hpc.rs:117-121
+
+
 def test_degenerate_batches(eng, oracle):
     """no reads at all; only empty reads; a single base; everything shorter than l"""
     for mode in SCALAR + (HM.Simd, HM.HpcSimd):
