@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--density", type=float, default=0.01)
     ap.add_argument("--mode", choices=["hpc", "regular"], default="hpc",
                     help="headline HashMode: hpc = the full fused path (HPC + ntHash + select + emit)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-side legs that follow the timed region: the CPU baseline and the PCIe-inclusive runs (profiling / A-B tools pass it)")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the run of the other scalar HashMode")
     ap.add_argument("--cpu-sample-reads", type=int, default=120_000, help="reads of the same workload timed on the CPU")
     ap.add_argument("--verify-reads", type=int, default=2000, help="reads drawn across the whole stream and compared field by field with the oracle (outside the timed region)")
@@ -393,7 +393,7 @@ def main():
 
     # ---- PCIe-inclusive legs (SURVEY 8d "what is timed (2)"): never `value`, reported beside it; N = 1, outside the timed region -----
     e2e = None
-    if rank == 0 and world == 1 and not args.no_end_to_end and args.workload == "c2":
+    if rank == 0 and world == 1 and not args.no_end_to_end and not args.no_cpu_baseline and args.workload == "c2":
         import ctypes as C
 
         ne = min(args.e2e_reads, n_reads)

@@ -541,37 +541,25 @@ __device__ __forceinline__ uint32_t div_tq(uint32_t x, uint32_t rcp) { return __
 
 // Back-map of one Hpc hit: tile-relative raw offsets of run heads x and x + l (x < R; x + l may be one of the
 // run heads that follow the tile).  The owner raw lane of a head is the last o with hbase[o] <= head; S.hl
-// brackets it to the raw lanes spanned by the head's hash lane.  Written so that the LDS reads of the two
-// look-ups are independent and can be in flight together (a chain of ~10 dependent reads per look-up cost
-// ~3.4k cycles per round of 64 hits).
+// brackets it to the raw lanes spanned by the head's hash lane.  Head x + l is found FROM head x: it lies l heads
+// further on, i.e. in the same raw lane or in the next one unless a lane holds fewer than l heads (long homopolymers:
+// those hits search again) -- round 2 ran two full searches side by side (~100 instructions each per round of 64 hits).
 template <class WL>
 __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l, uint32_t R, uint32_t halo_n,
                                             uint32_t Tq, uint32_t rcpTq, uint32_t &raw_x, uint32_t &raw_e) {
     const uint32_t y = x + l;
     const bool y_in = y < R;
-    const uint32_t yy = y_in ? y : x; // look-up 2 degenerates to look-up 1 when x + l lies after the tile
     (void)Tq;
-    const uint32_t q1 = div_tq(x, rcpTq), q2 = div_tq(yy, rcpTq);
-    uint32_t lo1 = S.hl[q1], hi1 = q1 < 63 ? S.hl[q1 + 1] : 63u;
-    uint32_t lo2 = S.hl[q2], hi2 = q2 < 63 ? S.hl[q2 + 1] : 63u;
-    // three candidates beyond lo at once; a wider bracket (long homopolymers: raw lanes without heads) loops
-    {
-        const uint32_t a1 = S.hbase[lo1 + 1 > 63 ? 63 : lo1 + 1], a2 = S.hbase[lo1 + 2 > 63 ? 63 : lo1 + 2], a3 = S.hbase[lo1 + 3 > 63 ? 63 : lo1 + 3];
-        const uint32_t b1 = S.hbase[lo2 + 1 > 63 ? 63 : lo2 + 1], b2 = S.hbase[lo2 + 2 > 63 ? 63 : lo2 + 2], b3 = S.hbase[lo2 + 3 > 63 ? 63 : lo2 + 3];
-        uint32_t o1 = lo1 + (uint32_t)(lo1 + 1 <= hi1 && a1 <= x) + (uint32_t)(lo1 + 2 <= hi1 && a2 <= x) + (uint32_t)(lo1 + 3 <= hi1 && a3 <= x);
-        uint32_t o2 = lo2 + (uint32_t)(lo2 + 1 <= hi2 && b1 <= yy) + (uint32_t)(lo2 + 2 <= hi2 && b2 <= yy) + (uint32_t)(lo2 + 3 <= hi2 && b3 <= yy);
-        while (o1 == lo1 + 3 && o1 < hi1 && S.hbase[o1 + 1] <= x) o1++, lo1++;
-        while (o2 == lo2 + 3 && o2 < hi2 && S.hbase[o2 + 1] <= yy) o2++, lo2++;
-        lo1 = o1;
-        lo2 = o2;
-    }
-    const uint32_t n1 = x - S.hbase[lo1], n2 = yy - S.hbase[lo2];
-    uint32_t w1[5], w2[5];
-#pragma unroll
-    for (int d = 0; d < 5; d++) {
-        w1[d] = S.fm[lo1][d];
-        w2[d] = S.fm[lo2][d];
-    }
+    auto owner = [&](uint32_t head) { // last raw lane o with hbase[o] <= head
+        const uint32_t q = div_tq(head, rcpTq);
+        uint32_t lo = S.hl[q];
+        const uint32_t hi = q < 63 ? S.hl[q + 1] : 63u;
+        // three candidates beyond lo at once; a wider bracket (long homopolymers: raw lanes without heads) loops
+        const uint32_t a1 = S.hbase[lo + 1 > 63 ? 63 : lo + 1], a2 = S.hbase[lo + 2 > 63 ? 63 : lo + 2], a3 = S.hbase[lo + 3 > 63 ? 63 : lo + 3];
+        uint32_t o = lo + (uint32_t)(lo + 1 <= hi && a1 <= head) + (uint32_t)(lo + 2 <= hi && a2 <= head) + (uint32_t)(lo + 3 <= hi && a3 <= head);
+        while (o == lo + 3 && o < hi && S.hbase[o + 1] <= head) o++, lo++;
+        return o;
+    };
     auto decode = [](const uint32_t (&w)[5], uint32_t n) { // raw offset (inside the lane's chunk) of the lane's n-th run head
         uint32_t g = 0, word = w[0];
 #pragma unroll
@@ -585,10 +573,33 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
         }
         return 32 * g + select_nth_32(word, n);
     };
+    const uint32_t lo1 = owner(x);
+    const uint32_t ln = lo1 < 63 ? lo1 + 1 : 63u; // the raw lane after it
+    const uint32_t hb1 = S.hbase[lo1], hbn = lo1 < 63 ? S.hbase[ln] : R, hbnn = lo1 < 62 ? S.hbase[lo1 + 2 > 63 ? 63 : lo1 + 2] : R;
+    uint32_t w1[5], wn[5];
+#pragma unroll
+    for (int d = 0; d < 5; d++) {
+        w1[d] = S.fm[lo1][d];
+        wn[d] = S.fm[ln][d];
+    }
+    const uint32_t n1 = x - hb1;
     raw_x = TILE_T * lo1 + decode(w1, n1);
+    const uint32_t m2 = n1 + l; // head x + l, counted from the first head of lane lo1
+    const bool same = m2 < hbn - hb1, next = !same && m2 - (hbn - hb1) < hbnn - hbn;
+    uint32_t w2[5];
+#pragma unroll
+    for (int d = 0; d < 5; d++) w2[d] = same ? w1[d] : wn[d];
+    uint32_t re = TILE_T * (same ? lo1 : ln) + decode(w2, same ? m2 : m2 - (hbn - hb1));
+    if (y_in && !same && !next) { // the next lane holds fewer than l heads beyond x: search for head x + l like for head x
+        const uint32_t lo2 = owner(y);
+        uint32_t w3[5];
+#pragma unroll
+        for (int d = 0; d < 5; d++) w3[d] = S.fm[lo2][d];
+        re = TILE_T * lo2 + decode(w3, y - S.hbase[lo2]);
+    }
     const uint32_t hx = y - R; // only meaningful when !y_in; validated hits guarantee hx < halo_n
     const uint32_t he = S.halo_pos[(!y_in && hx < halo_n) ? hx : 0];
-    raw_e = y_in ? TILE_T * lo2 + decode(w2, n2) : he;
+    raw_e = y_in ? re : he;
 }
 
 // Dense phase of one tile: hit bitmasks -> validated, ordered minimizer records in the tile's slab.  Returns their number

@@ -9,7 +9,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for mode in hpc regular; do
-  args="--mode $mode --no-other-mode --no-cpu-baseline --verify-reads 0"
+  args="--mode $mode --no-other-mode --no-cpu-baseline --no-end-to-end --verify-reads 0"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$mode/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $args > $out/$mode.stats.log 2>&1 || echo "stats pass failed ($mode)"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
