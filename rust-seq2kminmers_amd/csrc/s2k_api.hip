@@ -172,6 +172,9 @@ struct s2k_ctx {
     DevBuf in_bases2, in_off2, outbuf2;           // second set: s2k_extract double-buffers its sub-batches
     DevBuf count_tab;                             // s2k_count_device: the hash table (grow-only, like ws)
     hipStream_t s_in = nullptr, s_out = nullptr;  // s2k_extract: H2D of the next / D2H of the previous sub-batch
+    hipStream_t s_km = nullptr;                   // descriptor path: scan + k-min-mer kernel of chunk c run here, beside the minimizer kernel of chunk c+1
+    std::vector<hipEvent_t> chunk_ev;             // fork / per-chunk / join events of that pipeline (no timing)
+    uint32_t desc_chunks = 0;                     // chunks of tiles per call: 0 = default (6 for Hpc modes, 8 otherwise; S2K_DESC_CHUNKS overrides; 1 = no overlap)
     uint64_t host_batch = 1ull << 29;             // bases per sub-batch of s2k_extract (s2k_set_host_batch)
     Counts *d_counts = nullptr;
     Counts *h_counts = nullptr; // pinned
@@ -323,6 +326,16 @@ s2k_status enqueue(s2k_ctx *ctx) {
     // per-read counters and three scans (k > 32, tiles with more than 30 read starts, S2K_FLAG_LEGACY_PATH).
     const bool use_desc = !c.serial && !c.legacy && n_tiles >= 1 && n_reads >= 1 && c.sem.k <= 32;
     c.desc_run = use_desc;
+    // The call is cut into chunks of tiles: while the minimizer kernel works on chunk c+1, the scan and the k-min-mer kernel of
+    // chunk c run on a second stream (they need ~1/6 of the time and, being bound by latency, fit beside a kernel that leaves
+    // a quarter of the issue slots and some LDS free).  A chunk is at least a few tiles per resident wave.
+    uint32_t n_chunks = 1;
+    if (use_desc) {
+        n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? 6u : 8u); // measured: profiles/r03_ab_chunks.txt
+        const uint64_t min_chunk = 12 * 3072; // tiles (mean; the last chunk is a quarter of that)
+        if ((uint64_t)n_chunks * min_chunk > n_tiles) n_chunks = (uint32_t)(n_tiles / min_chunk);
+        if (n_chunks < 1) n_chunks = 1;
+    }
     unsigned long long *d_agg = nullptr, *d_scan = nullptr;
     TileMeta *d_meta = nullptr;
     TileState *d_state = nullptr;
@@ -335,7 +348,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
         mn_cnt = a.take<uint32_t>(n_reads + 1);
         mn_off = o.mn_off ? o.mn_off : a.take<uint64_t>(n_reads + 1);
         scan_tmp = a.take<uint64_t>(scan_tmp_bytes(n_reads > n_tiles ? n_reads : n_tiles) / sizeof(uint64_t) + 1);
-        pool_cursor = a.take<uint64_t>(CURSOR_WORDS);
+        pool_cursor = a.take<uint64_t>((size_t)CURSOR_WORDS * (use_desc ? n_chunks : 1));
         if (!c.serial) {
             tile_read0 = a.take<uint32_t>(n_tiles + 1);
             tile_cnt = a.take<uint32_t>(n_tiles + 1);
@@ -389,7 +402,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
     }
     S2K_TRY(hipMemsetAsync(ctx->d_counts, 0, sizeof(Counts), st), "memset counts");
     S2K_TRY(hipMemsetAsync(ctx->d_xor, 0, XOR_SHARDS * sizeof(uint64_t), st), "memset xor");
-    S2K_TRY(hipMemsetAsync(pool_cursor, 0, CURSOR_WORDS * sizeof(uint64_t), st), "memset cursors");
+    S2K_TRY(hipMemsetAsync(pool_cursor, 0, (size_t)CURSOR_WORDS * (use_desc ? n_chunks : 1) * sizeof(uint64_t), st), "memset cursors");
     // the read table is caller memory in HBM: checked on the device, first thing in the stream; the kernels below look at
     // the verdict (or clamp what they read from the table) and the host reports it in finish()
     S2K_TRY(launch_validate_read_off(c.d_read_off, n_reads, n_bases, &ctx->d_counts->bad_input, st), "read table validation");
@@ -431,14 +444,44 @@ s2k_status enqueue(s2k_ctx *ctx) {
             // (a tile without a single hash position -- Simd modes with bound 0 -- writes no word: zero = "nothing, passes p on")
             S2K_TRY(hipMemsetAsync(d_agg, 0, n_tiles * sizeof(unsigned long long), st), "memset tile words");
             if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
-            S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, nullptr,
-                                           nullptr, nullptr, ctx->d_counts, &dz, st),
-                    "tiled minimizer kernel");
-            if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
-            S2K_TRY(launch_desc_scan(n_tiles, dz, d_scan, ctx->d_counts, st), "tile word scan");
-            if (tm) S2K_TRY(hipEventRecord(ctx->ev[3], st), "event");
-            S2K_TRY(launch_desc_kminmers(n_tiles, n_reads, dz, rec, ctx->d_counts, st), "k-min-mer kernel");
-            if (tm) S2K_TRY(hipEventRecord(ctx->ev[4], st), "event");
+            if (n_chunks == 1) {
+                S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, nullptr,
+                                               nullptr, nullptr, ctx->d_counts, &dz, 0, st),
+                        "tiled minimizer kernel");
+                if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
+                if (tm) S2K_TRY(hipEventRecord(ctx->ev[3], st), "event");
+                S2K_TRY(launch_desc_scan(0, n_tiles, dz, d_scan, ctx->d_counts, st), "tile word scan");
+                S2K_TRY(launch_desc_kminmers(0, n_tiles, n_tiles, n_reads, dz, rec, ctx->d_counts, st), "k-min-mer kernel");
+                if (tm) S2K_TRY(hipEventRecord(ctx->ev[4], st), "event");
+            } else {
+                // fork: the second stream starts behind everything that is in the caller's stream so far
+                if (!ctx->s_km) S2K_TRY(hipStreamCreateWithFlags(&ctx->s_km, hipStreamNonBlocking), "stream create");
+                while (ctx->chunk_ev.size() < (size_t)n_chunks + 2) {
+                    hipEvent_t e;
+                    S2K_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event create");
+                    ctx->chunk_ev.push_back(e);
+                }
+                hipStream_t s2 = ctx->s_km;
+                S2K_TRY(hipEventRecord(ctx->chunk_ev[n_chunks], st), "event");
+                S2K_TRY(hipStreamWaitEvent(s2, ctx->chunk_ev[n_chunks], 0), "stream wait");
+                if (tm) S2K_TRY(hipEventRecord(ctx->ev[3], s2), "event");
+                // (equal chunks: tapering the last ones -- their k-min-mer kernel is the one nothing runs beside -- measured no better)
+                for (uint32_t ch = 0; ch < n_chunks; ch++) {
+                    const uint64_t T0 = n_tiles * ch / n_chunks, T1 = n_tiles * (ch + 1) / n_chunks;
+                    S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, T1, tile_read0, sem, rec,
+                                                   pool_cursor + (size_t)CURSOR_WORDS * ch, nullptr, nullptr, nullptr, ctx->d_counts, &dz, T0, st),
+                            "tiled minimizer kernel");
+                    S2K_TRY(hipEventRecord(ctx->chunk_ev[ch], st), "event");
+                    S2K_TRY(hipStreamWaitEvent(s2, ctx->chunk_ev[ch], 0), "stream wait");
+                    S2K_TRY(launch_desc_scan(T0, T1, dz, d_scan, ctx->d_counts, s2), "tile word scan");
+                    S2K_TRY(launch_desc_kminmers(T0, T1, n_tiles, n_reads, dz, rec, ctx->d_counts, s2), "k-min-mer kernel");
+                }
+                if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
+                if (tm) S2K_TRY(hipEventRecord(ctx->ev[4], s2), "event");
+                // join: what follows in the caller's stream (finalize, the next call) comes after the last k-min-mer kernel
+                S2K_TRY(hipEventRecord(ctx->chunk_ev[n_chunks + 1], s2), "event");
+                S2K_TRY(hipStreamWaitEvent(st, ctx->chunk_ev[n_chunks + 1], 0), "stream wait");
+            }
             S2K_TRY(launch_finalize(ctx->d_counts, ctx->d_xor, (const uint64_t *)&d_state[n_tiles].gmn, (const uint64_t *)&d_state[n_tiles].g,
                                     o.km_capacity, o.mn_capacity, st),
                     "finalize kernel");
@@ -449,7 +492,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
         }
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
         S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
-                                       tile_rec_off, tile_cnt, mn_cnt, ctx->d_counts, nullptr, st),
+                                       tile_rec_off, tile_cnt, mn_cnt, ctx->d_counts, nullptr, 0, st),
                 "tiled minimizer kernel");
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
         S2K_TRY(launch_scan_u32(tile_cnt, n_tiles, tile_goff, scan_tmp, 0, st), "scan");
@@ -608,6 +651,8 @@ s2k_ctx *s2k_create(int device, s2k_status *status) {
         return nullptr;
     }
     memset(ctx->h_counts, 0, sizeof(Counts));
+    if (const char *e = getenv("S2K_DESC_CHUNKS")) // tuning / A-B runs: chunks of tiles per call on the descriptor path (1 = no second stream)
+        if (atoi(e) >= 1 && atoi(e) <= 64) ctx->desc_chunks = (uint32_t)atoi(e);
     *status = S2K_OK;
     return ctx;
 }
@@ -625,6 +670,8 @@ void s2k_destroy(s2k_ctx *ctx) {
     ctx->in_off2.release();
     ctx->outbuf2.release();
     ctx->count_tab.release();
+    if (ctx->s_km) (void)hipStreamDestroy(ctx->s_km);
+    for (hipEvent_t e : ctx->chunk_ev) (void)hipEventDestroy(e);
     if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
     if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -636,6 +683,7 @@ void s2k_destroy(s2k_ctx *ctx) {
 }
 
 s2k_status s2k_set_stream(s2k_ctx *ctx, void *hip_stream) {
+    // (the descriptor path's second stream forks from and joins this one with events, call by call)
     if (!ctx) return S2K_ERR_INVALID_ARG;
     if (ctx->pending) {
         s2k_status st = finish(ctx, nullptr);

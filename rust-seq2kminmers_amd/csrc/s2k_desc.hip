@@ -81,10 +81,16 @@ __global__ __launch_bounds__(256) void desc_scan_reduce(const unsigned long long
 }
 // top level (at most a few hundred words): one wave walks it in batches of 64 and leaves the state BEFORE every entry
 __global__ __launch_bounds__(64) void desc_scan_top(const unsigned long long *__restrict__ in, uint64_t n, uint32_t K1,
-                                                    unsigned long long *__restrict__ states, const Counts *__restrict__ counts) {
+                                                    unsigned long long *__restrict__ states, const TileState *__restrict__ init,
+                                                    const Counts *__restrict__ counts) {
     const int lane = threadIdx.x;
     if (scan_off(counts)) return;
     PairState s{0, 0, 0};
+    if (init) { // the totals the scan of the tiles before this range left: {p << 48 | G, minimizers}
+        s.G = init->g & M48;
+        s.p = (uint32_t)(init->g >> 48) & 63u;
+        s.Gmn = init->gmn;
+    }
     for (uint64_t b0 = 0; b0 < n; b0 += 64) {
         const uint64_t i = b0 + lane;
         const AggF inc = wave_scan_agg(i < n ? ld_agg(in + 4 * i) : agg_identity(), lane, K1);
@@ -134,9 +140,9 @@ __global__ __launch_bounds__(256) void desc_scan_expand(const unsigned long long
         if constexpr (PACKED) {
             out_tiles[i].g = ((unsigned long long)mine.p << 48) | mine.G;
             out_tiles[i].gmn = mine.Gmn;
-            if (i + 1 == n) { // the totals
+            if (i + 1 == n) { // the totals, in the form of a tile state: the scan of the next range of tiles starts from them
                 const PairState tot = applied(s0, inc, K1);
-                out_tiles[n].g = tot.G;
+                out_tiles[n].g = ((unsigned long long)tot.p << 48) | tot.G;
                 out_tiles[n].gmn = tot.Gmn;
             }
         } else {
@@ -174,7 +180,8 @@ __device__ inline uint32_t dk_lane(uint32_t v, int src) { return (uint32_t)__bui
 
 // KT: compile-time k (the window loop is unrolled and reads the ring at constant offsets), or 0: run-time k <= 32
 template <int KT>
-__global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts) {
+__global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t tile_begin, uint64_t tile_end, uint64_t n_tiles, uint64_t n_reads, Desc dz,
+                                                                        Records rec, Counts *counts) {
     __shared__ unsigned long long s_ring[DK_WAVES][64 + DK_KMAX];
     __shared__ unsigned long long s_rs[DK_WAVES][META_SEGS];
     __shared__ int32_t s_adj[DK_WAVES][META_SEGS];
@@ -182,8 +189,8 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
     __shared__ uint32_t s_jcar[DK_WAVES][DK_KMAX];
     __shared__ uint32_t s_cum[DK_WAVES][64];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: per-tile values are scalar
-    const uint64_t t = (uint64_t)blockIdx.x * DK_WAVES + w;
-    if (t >= n_tiles) return; // whole waves leave together; no block-level barrier below
+    const uint64_t t = tile_begin + (uint64_t)blockIdx.x * DK_WAVES + w;
+    if (t >= tile_end) return; // whole waves leave together; no block-level barrier below
     // ---- round trip 1: everything whose address depends on nothing loaded -- the words of this tile and of the 63 before it,
     //      its state, its segment list, and its first 64 records under the assumption that they sit in the tile's own slab
     const uint32_t off_flags = counts->need_legacy | counts->bad_input | counts->pool_overflow;
@@ -358,28 +365,32 @@ size_t desc_scan_tmp_words(uint64_t n_tiles) {
     return 7 * n1 + 7 * n2 + 16;
 }
 
-hipError_t launch_desc_scan(uint64_t n_tiles, Desc dz, unsigned long long *scan_tmp, const Counts *counts, hipStream_t st) {
-    if (n_tiles == 0) return hipSuccess;
-    const uint64_t n1 = (n_tiles + 63) / 64, n2 = (n1 + 63) / 64;
+hipError_t launch_desc_scan(uint64_t tile_begin, uint64_t tile_end, Desc dz, unsigned long long *scan_tmp, const Counts *counts, hipStream_t st) {
+    if (tile_end <= tile_begin) return hipSuccess;
+    const uint64_t n = tile_end - tile_begin;
+    const uint64_t n1 = (n + 63) / 64, n2 = (n1 + 63) / 64;
     unsigned long long *w1 = scan_tmp, *s1 = w1 + 4 * n1, *w2 = s1 + 3 * n1, *s2 = w2 + 4 * n2;
     const uint32_t K1 = dz.k - 1;
-    hipLaunchKernelGGL(desc_scan_reduce<true>, dim3((unsigned)((n1 + 3) / 4)), dim3(256), 0, st, dz.agg, n_tiles, K1, w1, counts);
+    const unsigned long long *agg = dz.agg + tile_begin;
+    TileState *state = dz.state + tile_begin;
+    hipLaunchKernelGGL(desc_scan_reduce<true>, dim3((unsigned)((n1 + 3) / 4)), dim3(256), 0, st, agg, n, K1, w1, counts);
     hipLaunchKernelGGL(desc_scan_reduce<false>, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, st, w1, n1, K1, w2, counts);
-    hipLaunchKernelGGL(desc_scan_top, dim3(1), dim3(64), 0, st, w2, n2, K1, s2, counts);
+    hipLaunchKernelGGL(desc_scan_top, dim3(1), dim3(64), 0, st, w2, n2, K1, s2, tile_begin ? (const TileState *)state : (const TileState *)nullptr, counts);
     hipLaunchKernelGGL(desc_scan_expand<false>, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, st, w1, n1, K1, s2, s1, (TileState *)nullptr, counts);
-    hipLaunchKernelGGL(desc_scan_expand<true>, dim3((unsigned)((n1 + 3) / 4)), dim3(256), 0, st, dz.agg, n_tiles, K1, s1, (unsigned long long *)nullptr,
-                       dz.state, counts);
+    hipLaunchKernelGGL(desc_scan_expand<true>, dim3((unsigned)((n1 + 3) / 4)), dim3(256), 0, st, agg, n, K1, s1, (unsigned long long *)nullptr, state,
+                       counts);
     return hipGetLastError();
 }
 
-hipError_t launch_desc_kminmers(uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts, hipStream_t st) {
-    if (n_tiles == 0) return hipSuccess;
+hipError_t launch_desc_kminmers(uint64_t tile_begin, uint64_t tile_end, uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts,
+                                hipStream_t st) {
+    if (tile_end <= tile_begin) return hipSuccess;
     if (dz.k == 0 || dz.k > (uint32_t)DK_KMAX || rec.slab_cap < 64) return hipErrorInvalidValue;
-    const dim3 g((unsigned)((n_tiles + DK_WAVES - 1) / DK_WAVES)), b(64 * DK_WAVES);
+    const dim3 g((unsigned)((tile_end - tile_begin + DK_WAVES - 1) / DK_WAVES)), b(64 * DK_WAVES);
     switch (dz.k) { // the benchmark's k and the reference demo's (src/main.rs:13-48) get an unrolled window loop
-    case 10: hipLaunchKernelGGL(desc_kminmer_kernel<10>, g, b, 0, st, n_tiles, n_reads, dz, rec, counts); break;
-    case 5: hipLaunchKernelGGL(desc_kminmer_kernel<5>, g, b, 0, st, n_tiles, n_reads, dz, rec, counts); break;
-    default: hipLaunchKernelGGL(desc_kminmer_kernel<0>, g, b, 0, st, n_tiles, n_reads, dz, rec, counts); break;
+    case 10: hipLaunchKernelGGL(desc_kminmer_kernel<10>, g, b, 0, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
+    case 5: hipLaunchKernelGGL(desc_kminmer_kernel<5>, g, b, 0, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
+    default: hipLaunchKernelGGL(desc_kminmer_kernel<0>, g, b, 0, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
     }
     return hipGetLastError();
 }

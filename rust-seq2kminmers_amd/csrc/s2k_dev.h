@@ -245,16 +245,20 @@ hipError_t launch_finalize(Counts *counts, const uint64_t *xor_shards, const uin
 
 hipError_t launch_tile_index(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles,
                              uint32_t *tile_read0, hipStream_t st);
-// desc != nullptr: descriptor path (8-byte records in rec.hash / rec.j, agg word + meta per tile; tile_rec_off / tile_cnt / mn_cnt unused)
+// desc != nullptr: descriptor path (8-byte records in rec.hash / rec.j, agg word + meta per tile; tile_rec_off / tile_cnt / mn_cnt unused).
+// The launch works on the tiles [tile_begin, n_tiles); pool_cursor must be zeroed (CURSOR_WORDS words) for every launch.
 hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                   uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec,
                                   uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
-                                  Counts *counts, const Desc *desc, hipStream_t st);
-// descriptor path: (G, p) of every tile from the tile words (state[n_tiles] = the totals), then the k-min-mers
-hipError_t launch_desc_scan(uint64_t n_tiles, Desc dz, unsigned long long *scan_tmp /* desc_scan_tmp_words(n_tiles) */, const Counts *counts,
-                            hipStream_t st);
+                                  Counts *counts, const Desc *desc, uint64_t tile_begin, hipStream_t st);
+// descriptor path, for the tiles [tile_begin, tile_end): (G, p) of every tile from the tile words -- starting from state[tile_begin]
+// (the totals a previous call for the tiles before left there; zeros for tile_begin == 0) and leaving the totals in state[tile_end] --
+// then the k-min-mers of those tiles
+hipError_t launch_desc_scan(uint64_t tile_begin, uint64_t tile_end, Desc dz, unsigned long long *scan_tmp /* desc_scan_tmp_words(n_tiles) */,
+                            const Counts *counts, hipStream_t st);
 size_t desc_scan_tmp_words(uint64_t n_tiles);
-hipError_t launch_desc_kminmers(uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts, hipStream_t st);
+hipError_t launch_desc_kminmers(uint64_t tile_begin, uint64_t tile_end, uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts,
+                                hipStream_t st);
 
 hipError_t launch_hpc_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint32_t *run_cnt, hipStream_t st,
                             bool rle = false);

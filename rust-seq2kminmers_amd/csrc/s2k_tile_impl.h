@@ -1073,7 +1073,9 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
     uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
     uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts,
-    unsigned long long *__restrict__ d_agg, TileMeta *__restrict__ d_meta, uint32_t K1) {
+    unsigned long long *__restrict__ d_agg, TileMeta *__restrict__ d_meta, uint32_t K1, uint64_t tile_begin) {
+    // (this launch works on the tiles [tile_begin, n_tiles): the descriptor path cuts a call into a few chunks of tiles so that
+    // the k-min-mer kernel of one chunk runs, on a second stream, beside the minimizer kernel of the next)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     using WL = WaveLdsT<HPC>;
     uint2 *tab = reinterpret_cast<uint2 *>(smem);
@@ -1092,7 +1094,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     WL &S = *reinterpret_cast<WL *>(smem + TABLE_BYTES + (size_t)w * sizeof(WL));
     uint8_t *D = S.buf + HS_OFF;
     const uint64_t n_waves = (uint64_t)gridDim.x * TW;
-    uint64_t t = (uint64_t)blockIdx.x * TW + w;
+    uint64_t t = tile_begin + (uint64_t)blockIdx.x * TW + w;
     if (t >= n_tiles) return;
     if (__builtin_amdgcn_readfirstlane((int)counts->bad_input)) return; // malformed read table (validate_read_off_kernel): touch nothing
     uint64_t stamp = __builtin_amdgcn_s_memtime();
@@ -1164,7 +1166,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     // tn / tnn: the next two tiles of this wave; >= n_tiles: none.  Dynamic tiles are numbered from dyn0 on: cursor g deals
     // dyn0 + g, dyn0 + g + TILE_CURSORS, ... (pool_cursor[16 + 16 g], zeroed by the host before the launch).
     uint64_t tn = t + n_waves, tnn = t + 2 * n_waves;
-    const uint64_t dyn0 = 3 * n_waves;
+    const uint64_t dyn0 = tile_begin + 3 * n_waves;
     const uint32_t cur_g = (uint32_t)((blockIdx.x * TW + w) % TILE_CURSORS);
     unsigned int *const cursors = (unsigned int *)(pool_cursor + 16); // 32-bit draws (a 64-bit result's dead upper half would be
                                                                        // reused early and pull a vmcnt(0) in front of the compaction); cursor g = word 32 g
@@ -1388,7 +1390,7 @@ __global__ __launch_bounds__(256) void tile_index_kernel(const uint64_t *__restr
 template <int L, bool HPC, bool DESC>
 hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                            uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
-                           uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts, const Desc *desc) {
+                           uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts, const Desc *desc, uint64_t tile_begin) {
     auto kern = tile_minimizer_kernel<L, HPC, DESC>;
     const int lds = block_lds_bytes<HPC>();
     // per instantiation AND per device: function attributes and occupancy belong to the device the module is loaded on
@@ -1418,12 +1420,12 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
         n_cu_d[dev] = prop.multiProcessorCount;
     }
     const int n_cu = n_cu_d[dev], per_cu = per_cu_d[dev];
-    uint64_t blocks = (n_tiles + TW - 1) / TW;
+    uint64_t blocks = (n_tiles - tile_begin + TW - 1) / TW;
     const uint64_t resident = (uint64_t)n_cu * per_cu;
     if (blocks > resident) blocks = resident; // persistent: waves loop over the remaining tiles
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * TW), lds, st, bases, read_off, n_reads, n_bases, n_tiles,
                        tile_read0, sem, rec, pool_cursor, tile_rec_off, tile_cnt, mn_cnt, counts, desc ? desc->agg : nullptr,
-                       desc ? desc->meta : nullptr, desc ? desc->k - 1u : 0u);
+                       desc ? desc->meta : nullptr, desc ? desc->k - 1u : 0u, tile_begin);
     return hipGetLastError();
 }
 
@@ -1431,10 +1433,10 @@ template <int L>
 hipError_t launch_tiles_l(bool hpc, hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
                           uint64_t n_bases, uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec,
                           uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
-                          Counts *counts, const Desc *desc) {
+                          Counts *counts, const Desc *desc, uint64_t tile_begin) {
 #define S2K_GO(H, F)                                                                                                       \
     launch_tiles_lh<L, H, F>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, tile_rec_off, \
-                             tile_cnt, mn_cnt, counts, desc)
+                             tile_cnt, mn_cnt, counts, desc, tile_begin)
     if (desc) return hpc ? S2K_GO(true, true) : S2K_GO(false, true);
     return hpc ? S2K_GO(true, false) : S2K_GO(false, false);
 #undef S2K_GO

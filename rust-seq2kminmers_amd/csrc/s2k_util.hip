@@ -149,10 +149,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(Counts *counts, const uin
     __syncthreads();
     if (threadIdx.x == 0) {
         counts->xor_hash = sh[0] ^ sh[1] ^ sh[2] ^ sh[3];
-        counts->n_minimizers = *mn_total;
-        counts->n_kminmers = *km_total;
-        counts->km_overflow = (*km_total > km_capacity) ? 1u : 0u;
-        counts->mn_overflow = (mn_capacity != 0 && *mn_total > mn_capacity) ? 1u : 0u;
+        const uint64_t M48 = (1ull << 48) - 1ull; // (the descriptor path keeps p in the bits above: zero behind the last tile anyway)
+        const uint64_t mn = *mn_total & M48, km = *km_total & M48;
+        counts->n_minimizers = mn;
+        counts->n_kminmers = km;
+        counts->km_overflow = (km > km_capacity) ? 1u : 0u;
+        counts->mn_overflow = (mn_capacity != 0 && mn > mn_capacity) ? 1u : 0u;
     }
 }
 
