@@ -371,8 +371,8 @@ def main():
     # divided by the HIP-event time of ALL kernels of the step (tile index, minimizer kernel, scans, k-min-mer kernel).
     alg_bytes = counts["n_bases"] + 17 * counts["n_kminmers"] + 16 * (n_reads + 1)
     achieved = alg_bytes / (pipe_ms * 1e-3) / 1e9
-    # the dominant kernel on its own: it reads the bases and the read table once and writes 16 B per minimizer record
-    kern_bytes = counts["n_bases"] + 16 * counts["n_minimizers"] + 8 * (n_reads + 1)
+    # the dominant kernel on its own: it reads the bases and the read table once and writes 8 B per minimizer record (16 B on the legacy path)
+    kern_bytes = counts["n_bases"] + (16 if args.legacy_path else 8) * counts["n_minimizers"] + 8 * (n_reads + 1)
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath) and args.workload == "c2":
@@ -389,6 +389,9 @@ def main():
                 "kernel": "tile_minimizer_kernel<%d,%s>" % (args.l, "hpc" if mode == pkg.HashMode.Hpc else "regular"),
                 "kernel_ms": round(min_ms, 3), "kernel_bytes": int(kern_bytes),
                 "kernel_frac": round(kern_bytes / (min_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kminmer_kernel_ms": round(km_ms, 3),
+                "kminmer_exposed_ms": round(max(pipe_ms - min_ms, 0.0), 3),
+                "overlap": None if args.legacy_path else "the call is cut into chunks of tiles; scan + k-min-mer kernel of chunk c run on a second stream beside the "
+                           "minimizer kernel of chunk c+1: kernel_ms and kminmer_kernel_ms are first-start-to-last-end spans that overlap, kminmer_exposed_ms = time_ms - kernel_ms",
                 "limiter": "integer VALU issue, not HBM: see DESIGN.md 3.1 and tools/experiments/valu_rate.hip"}
 
     # ---- PCIe-inclusive legs (SURVEY 8d "what is timed (2)"): never `value`, reported beside it; N = 1, outside the timed region -----

@@ -211,7 +211,10 @@ s2k_status s2k_partition_device(s2k_ctx *ctx, const uint64_t *d_hash, uint64_t n
  * absolute base index; same function as oracle/s2k_oracle.c:s2k_oracle_synth_bases). */
 s2k_status s2k_synth_bases_device(s2k_ctx *ctx, uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_bases);
 /* Duration in ms of the kernels of the last s2k_extract_device call, measured with HIP events on the
- * context's stream: which: 0 = whole pipeline, 1 = the minimizer kernel (dominant), 2 = k-min-mer kernel. */
+ * context's stream: which: 0 = whole pipeline (first kernel's start to the last one's end), 1 = the minimizer kernel (dominant; the
+ * descriptor path launches it once per chunk of tiles: first start to last end), 2 = scan + k-min-mer kernels (first start to last
+ * end; on the descriptor path they run on a second stream BESIDE the minimizer kernel of the next chunk, so 1 and 2 overlap and
+ * do not add up to 0). */
 s2k_status s2k_last_kernel_ms(s2k_ctx *ctx, int which, float *ms);
 s2k_status s2k_enable_timing(s2k_ctx *ctx, int on);
 /* Sum over every s2k_extract_device call since s2k_enable_timing(ctx, 1) of the same HIP-event
