@@ -332,7 +332,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
     uint32_t n_chunks = 1;
     if (use_desc) {
         n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? 6u : 8u); // measured: profiles/r03_ab_chunks.txt
-        const uint64_t min_chunk = 12 * 3072; // tiles (mean; the last chunk is a quarter of that)
+        const uint64_t min_chunk = ctx->desc_chunks ? 64 : 12 * 3072; // tiles: a dozen per resident wave (a forced count -- tests -- only needs 64)
         if ((uint64_t)n_chunks * min_chunk > n_tiles) n_chunks = (uint32_t)(n_tiles / min_chunk);
         if (n_chunks < 1) n_chunks = 1;
     }

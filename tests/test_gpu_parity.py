@@ -760,6 +760,83 @@ def test_full_size_config5_whole_run_checksums(eng, oracle):
         assert sample_reads_compare(t, n, oracle, seed, 0, lambda r: (r * L, L), ids, 31, 10, 0.001, OMODE[mode], threads=threads) > 0
 
 
+def test_descriptor_and_legacy_paths_agree(eng, oracle):
+    """The default path (8-byte tile-relative records, tile words, scan, k-min-mer kernel without per-read tables; counts.path 0)
+    and the legacy one (16-byte records with the read index, per-read scans; path 2, S2K_FLAG_LEGACY_PATH) against the oracle and
+    against each other, with minimizer triples, on inputs that make the descriptor path work: reads that span many tiles, reads
+    that start exactly at a tile boundary, tiles without a minimizer, empty reads, k = 1 and k = 32."""
+    rng = np.random.default_rng(4242)
+    T = 9216
+    reads = [rand_read(rng, 3 * T, hp=0.1), rand_read(rng, T - 7), rand_read(rng, 7), b"", rand_read(rng, 2 * T), b"", b"",
+             rand_read(rng, 5 * T + 1, hp=0.3), b"A" * 20000, rand_read(rng, 40), rand_read(rng, 31), rand_read(rng, 32), rand_read(rng, 4 * T - 72)]
+    reads += [rand_read(rng, int(n), hp=0.15) for n in rng.integers(2000, 60000, size=60)]
+    for mode in (HM.Regular, HM.Hpc, HM.Simd, HM.HpcSimd):
+        for (l, k, d) in ((31, 10, 0.01), (31, 1, 0.02), (21, 32, 0.05), (12, 5, 0.001), (31, 10, 0.0002)):
+            a = compare(eng, oracle, reads, l, k, d, mode, expect_path="desc", tag="desc-path")
+            bases, off = pkg.pack_reads(reads)
+            b = eng.extract(bases, off, l, k, d, mode, want_minimizers=True, legacy=True)
+            assert b["counts"]["path"] == 2
+            for f in FIELDS + ("mn_off", "mn_j", "mn_jend", "mn_hash"):
+                assert (a[f] == b[f]).all(), (int(mode), l, k, d, f)
+
+
+def test_descriptor_path_falls_back_when_it_must(eng, oracle):
+    """What the descriptor path does not handle sends the whole call to the legacy path, transparently (counts.path 2): a tile with
+    more than 30 read starts (reads shorter than ~300 bases), k > 32, and an l-mer whose span does not fit 18 bits (a homopolymer of
+    more than 262 143 bases inside one Hpc l-mer)."""
+    rng = np.random.default_rng(99)
+    short = [rand_read(rng, int(n), hp=0.1) for n in rng.integers(40, 260, size=4000)]
+    compare(eng, oracle, short, 15, 3, 0.1, HM.Hpc, expect_path="legacy", tag="short-reads")
+    compare(eng, oracle, short, 15, 3, 0.1, HM.Regular, expect_path="legacy", tag="short-reads")
+    longish = [rand_read(rng, 30000, hp=0.1) for _ in range(8)]
+    compare(eng, oracle, longish, 21, 33, 0.05, HM.Hpc, expect_path="legacy", tag="k33")
+    compare(eng, oracle, longish, 21, 32, 0.05, HM.Hpc, expect_path="desc", tag="k32")
+    giant = rand_read(rng, 5000) + b"G" * 300000 + rand_read(rng, 5000)
+    got = compare(eng, oracle, [giant, rand_read(rng, 20000)], 12, 3, 0.5, HM.Hpc, expect_path="legacy", tag="giant-homopolymer")
+    assert int((got["end"].astype(np.int64) - got["start"].astype(np.int64)).max()) > 300000
+    compare(eng, oracle, [giant, rand_read(rng, 20000)], 12, 3, 0.5, HM.Regular, expect_path="desc", tag="giant-homopolymer-regular")
+
+
+def test_chunked_pipeline_equals_single_launch(oracle):
+    """The descriptor path cuts a call into chunks of tiles (minimizer kernel of chunk c+1 beside the scan + k-min-mer kernel of chunk
+    c on a second stream).  S2K_DESC_CHUNKS = 1 (no second stream), 3 and 13 must give the same bytes as the default on a batch
+    whose reads straddle every chunk boundary; run in child processes because the variable is read when a context is created."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+from s2k_loader import import_package
+pkg = import_package()
+eng = pkg.Engine(0)
+rng = np.random.default_rng(7)
+lens = rng.integers(3000, 90000, size=12000)
+off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(off[-1]))]
+bases = np.repeat(bases, rng.choice([1, 1, 1, 2, 5], size=len(bases)))[: int(off[-1])].copy()
+h = hashlib.sha256()
+for mode in (0, 1):
+    r = eng.extract(bases, off, 31, 10, 0.01, mode, want_minimizers=True)
+    assert r["counts"]["path"] == 0
+    for f in ("km_off", "hash", "start", "end", "rev", "mn_off", "mn_j", "mn_jend", "mn_hash"):
+        h.update(r[f].tobytes())
+    print(mode, r["n"], r["n_minimizers"])
+print(h.hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for chunks in ("", "1", "3", "13"):
+        env = dict(os.environ)
+        env.pop("S2K_DESC_CHUNKS", None)
+        if chunks:
+            env["S2K_DESC_CHUNKS"] = chunks
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[chunks] = p.stdout.strip().splitlines()
+    assert outs[""] == outs["1"] == outs["3"] == outs["13"], outs
+    assert int(outs[""][0].split()[1]) > 1_000_000  # ~500 Mbp: 54 000 tiles, several chunks by default
+
+
 def test_minimizer_iterator_facades(eng, oracle, ecoli):
     """The crate's minimizer iterators (re-exported at src/lib.rs:6-13) as Python classes over S2K_FLAG_WANT_MINIMIZERS, against
     the oracle's minimizers in all four modes: NtHashHPCIterator yields (start, end, hash) (src/nthash_hpc.rs:193),
