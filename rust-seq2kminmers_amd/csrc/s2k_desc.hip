@@ -252,6 +252,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
         if ((uint32_t)lane < p_in) {
             const uint32_t q = (uint32_t)lane;
             int ti = 1;
+#pragma nounroll // (the first tile back as a rule: unrolled 63 times this search was most of the kernel's code)
             while (ti < 64 && s_cum[w][ti] <= q) ti++; // first tile back whose cumulative count exceeds q
             uint64_t u = 0;
             uint32_t idx = 0, Nu = 0;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
             npos = rec.j[base + i + 64];
         }
         uint32_t c = 0;
+#pragma nounroll // (one or two read starts per tile as a rule: unrolled 31 times, the loop was most of the kernel's code)
         for (uint32_t s = 1; s <= nb; s++) c += (s_segb[w][s] <= i); // wave-uniform trip count, LDS broadcast
         const uint64_t rstart = s_rs[w][c];
         const uint32_t j = (uint32_t)(t0 + (pos & 0x3FFFu) - rstart);
@@ -306,26 +308,59 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
         // rank of the hit inside its read, capped: the window that ENDS here exists iff k-1 minimizers of the read precede it
         const uint32_t before = (c == 0 ? p_in : 0u) + (i - s_segb[w][c]);
         const bool win = act && before >= K1;
-        // F = XOR rotl(x_m, k-1-m), Rv = XOR rotl(x_m, m) over the window (src/lib.rs:238-249, closed form :275-288), by Horner
-        // with rotations by one: f <- rotl(f, 1) ^ x_m;  r <- rotr(r, 1) ^ x_m, Rv = rotl(r, k-1).  ring[lane + m] = hit i - (k-1) + m
+        // F = XOR rotl(x_m, k-1-m), Rv = XOR rotl(x_m, m) over the window (src/lib.rs:238-249, closed form :275-288); ring[lane + m] = hit i - (k-1) + m
         uint32_t fl = 0, fh = 0, rl = 0, rh = 0;
-        auto step = [&](uint32_t mm) {
-            const uint64_t xw = s_ring[w][lane + mm];
-            const uint32_t xl = (uint32_t)xw, xh = (uint32_t)(xw >> 32);
-            const uint32_t nfh = __builtin_amdgcn_alignbit(fh, fl, 31), nfl = __builtin_amdgcn_alignbit(fl, fh, 31);
-            const uint32_t nrl = __builtin_amdgcn_alignbit(rh, rl, 1), nrh = __builtin_amdgcn_alignbit(rl, rh, 1);
-            fl = nfl ^ xl;
-            fh = nfh ^ xh;
-            rl = nrl ^ xl;
-            rh = nrh ^ xh;
-        };
+        uint64_t rvv;
         if constexpr (KFIX) {
+            // compile-time k: every x_m is rotated by its own constant (two v_alignbit each for F and for Rv, none for a rotation by 0)
+            // and the terms are folded two at a time with the three-input xor of gfx950 (v_bitop3_b32)
+            uint32_t xl[KT], xh[KT];
 #pragma unroll
-            for (uint32_t mm = 0; mm < (uint32_t)KT; mm++) step(mm);
+            for (int mm = 0; mm < KT; mm++) {
+                const uint64_t xw = s_ring[w][lane + mm];
+                xl[mm] = (uint32_t)xw;
+                xh[mm] = (uint32_t)(xw >> 32);
+            }
+            auto rot_lo = [](uint32_t lo, uint32_t hi, int c) { return c ? __builtin_amdgcn_alignbit(lo, hi, 32 - c) : lo; }; // low word of rotl64(x, c), c < 32
+            auto rot_hi = [](uint32_t lo, uint32_t hi, int c) { return c ? __builtin_amdgcn_alignbit(hi, lo, 32 - c) : hi; };
+            uint32_t al[KT], ah[KT], bl[KT], bh[KT];
+#pragma unroll
+            for (int mm = 0; mm < KT; mm++) {
+                al[mm] = rot_lo(xl[mm], xh[mm], KT - 1 - mm); // F: rotl(x_m, k-1-m)
+                ah[mm] = rot_hi(xl[mm], xh[mm], KT - 1 - mm);
+                bl[mm] = rot_lo(xl[mm], xh[mm], mm);          // Rv: rotl(x_m, m)
+                bh[mm] = rot_hi(xl[mm], xh[mm], mm);
+            }
+            fl = al[0], fh = ah[0], rl = bl[0], rh = bh[0];
+#pragma unroll
+            for (int mm = 1; mm + 1 < KT; mm += 2) {
+                fl = xor3(fl, al[mm], al[mm + 1]);
+                fh = xor3(fh, ah[mm], ah[mm + 1]);
+                rl = xor3(rl, bl[mm], bl[mm + 1]);
+                rh = xor3(rh, bh[mm], bh[mm + 1]);
+            }
+            if constexpr (KT % 2 == 0) {
+                fl ^= al[KT - 1];
+                fh ^= ah[KT - 1];
+                rl ^= bl[KT - 1];
+                rh ^= bh[KT - 1];
+            }
+            rvv = ((uint64_t)rh << 32) | rl;
         } else {
-            for (uint32_t mm = 0; mm < k; mm++) step(mm);
+            // run-time k: Horner with rotations by one: f <- rotl(f, 1) ^ x_m;  r <- rotr(r, 1) ^ x_m, Rv = rotl(r, k-1)
+            for (uint32_t mm = 0; mm < k; mm++) {
+                const uint64_t xw = s_ring[w][lane + mm];
+                const uint32_t xl = (uint32_t)xw, xh = (uint32_t)(xw >> 32);
+                const uint32_t nfh = __builtin_amdgcn_alignbit(fh, fl, 31), nfl = __builtin_amdgcn_alignbit(fl, fh, 31);
+                const uint32_t nrl = __builtin_amdgcn_alignbit(rh, rl, 1), nrh = __builtin_amdgcn_alignbit(rl, rh, 1);
+                fl = nfl ^ xl;
+                fh = nfh ^ xh;
+                rl = nrl ^ xl;
+                rh = nrh ^ xh;
+            }
+            rvv = rotl64(((uint64_t)rh << 32) | rl, K1);
         }
-        const uint64_t f = ((uint64_t)fh << 32) | fl, rvv = rotl64(((uint64_t)rh << 32) | rl, K1);
+        const uint64_t f = ((uint64_t)fh << 32) | fl;
         // start = j of the window's first minimizer: k-1 hits back, in this round or the one before it
         const int src = ((lane - (int)K1) & 63) << 2;
         const uint32_t jsame = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)j), jbefore = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)jprev);

@@ -27,6 +27,18 @@ __host__ __device__ inline uint32_t seed_rc_simd(uint32_t c) {
     return n == 1 ? SEED_T : n == 3 ? SEED_G : n == 7 ? SEED_C : n == 4 ? SEED_A : 0u;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// a ^ b ^ c in ONE instruction: gfx950's three-input bit operation (truth table 0x96).  The compiler keeps two v_xor_b32 (each
+// cheaper than a VOP3 instruction; the pair is not: 4.1 vs 3.1 issue cycles at three waves per SIMD, tools/experiments/valu_rate.hip)
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#else
+__host__ __device__ inline uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; } // (the host pass only parses the kernels)
+#endif
+
 __host__ __device__ inline uint32_t rotl32(uint32_t x, uint32_t r) { r &= 31u; return (x << r) | (x >> ((32u - r) & 31u)); }
 __host__ __device__ inline uint32_t rotr32(uint32_t x, uint32_t r) { r &= 31u; return (x >> r) | (x << ((32u - r) & 31u)); }
 __host__ __device__ inline uint64_t rotl64(uint64_t x, uint32_t r) { r &= 63u; return (x << r) | (x >> ((64u - r) & 63u)); }

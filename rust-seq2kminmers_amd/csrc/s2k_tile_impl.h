@@ -235,8 +235,8 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * (
             constexpr int P = S - L;
             const uint32_t hv = fh < rh ? fh : rh;                              // canonical (src/nthash_hpc.rs:276)
             hit_track(hv, bound, caps[P / CAPP], bits);                         // hv <= bound (src/nthash_hpc.rs:277 / src/lib.rs:228)
-            fh = __builtin_rotateleft32(fh, 1) ^ EO[P].x ^ EI[S].x;             // src/nthash_hpc.rs:245
-            rh = __builtin_rotateright32(rh, 1) ^ EO[P].y ^ EI[S].y;            // src/nthash_hpc.rs:247-249
+            fh = xor3(__builtin_rotateleft32(fh, 1), EO[P].x, EI[S].x);         // src/nthash_hpc.rs:245
+            rh = xor3(__builtin_rotateright32(rh, 1), EO[P].y, EI[S].y);        // src/nthash_hpc.rs:247-249
             if constexpr (P % 16 == 15) {
                 close_piece<P>(bits, raw);
                 if (P / 16 + 1 >= np) return; // wave-uniform: the (compacted) tile is shorter than 144 bases per lane
@@ -878,14 +878,17 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
 #pragma unroll
                     for (uint32_t ii = 0; ii < 4; ii++)
                         if (h0 + ii < PER) ti[ii] = tab_in(tab, by[ii]); // IN pair = {h[c], rotl(rc[c], l-1)}
+                    uint32_t tf[4] = {0, 0, 0, 0}, tr[4] = {0, 0, 0, 0};
 #pragma unroll
                     for (uint32_t ii = 0; ii < 4; ii++)
                         if (h0 + ii < PER) {
                             const uint32_t i = i0 + h0 + ii, rot = (uint32_t)L - 1u - i;
                             const bool valid = 3 * PER + h0 + ii < (uint32_t)L || i < (uint32_t)L; // only the last quarter can run past l
-                            f ^= valid ? rotl32(ti[ii].x, rot) : 0u;
-                            r ^= valid ? rotr32(ti[ii].y, rot) : 0u;
+                            tf[ii] = valid ? rotl32(ti[ii].x, rot) : 0u;
+                            tr[ii] = valid ? rotr32(ti[ii].y, rot) : 0u;
                         }
+                    f = xor3(xor3(f, tf[0], tf[1]), tf[2], tf[3]); // two terms per instruction (v_bitop3_b32)
+                    r = xor3(xor3(r, tr[0], tr[1]), tr[2], tr[3]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
