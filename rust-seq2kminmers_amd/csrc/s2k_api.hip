@@ -156,6 +156,7 @@ struct Call { // everything needed to (re-)enqueue one extraction
     uint32_t bound = 0;
     bool serial = false;
     bool desc_run = false; // what the last enqueue() took
+    bool full_runs = false; // HpcSimd: the runs of every read are counted in a pre-pass (a look-back from tile to tile gave up: need_runs; S2K_FULL_RUNS)
     bool legacy = false;   // S2K_FLAG_LEGACY_PATH, or the descriptor path met something it does not handle: the (re-)run takes the legacy records
     uint64_t pool_cap = 0; // serial: dense record capacity; tiled: capacity of the overflow region
     uint64_t slab_cap = 0; // tiled: records per tile slab
@@ -175,6 +176,8 @@ struct s2k_ctx {
     hipStream_t s_km = nullptr;                   // descriptor path: scan + k-min-mer kernel of chunk c run here, beside the minimizer kernel of chunk c+1
     std::vector<hipEvent_t> chunk_ev;             // fork / per-chunk / join events of that pipeline (no timing)
     uint32_t desc_chunks = 0;                     // chunks of tiles per call: 0 = default (6 for Hpc modes, 8 otherwise; S2K_DESC_CHUNKS overrides; 1 = no overlap)
+    bool force_full_runs = false;                 // S2K_FULL_RUNS=1 (A/B, tests): HpcSimd counts the runs of every read in a pre-pass instead of looking back from tile to tile
+    bool trace = false;                           // S2K_TRACE: one line on stderr whenever a call is run again (record pool too small, a fall-back to another path)
     uint64_t host_batch = 1ull << 29;             // bases per sub-batch of s2k_extract (s2k_set_host_batch)
     Counts *d_counts = nullptr;
     Counts *h_counts = nullptr; // pinned
@@ -340,7 +343,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
     TileMeta *d_meta = nullptr;
     TileState *d_state = nullptr;
     const uint64_t n_runblk = n_bases / 256 + 1;
-    uint32_t *run_blk = nullptr, *read_runs = nullptr;
+    uint32_t *run_blk = nullptr, *read_runs = nullptr, *tile_heads = nullptr;
     uint64_t *run_off = nullptr, *run_tmp = nullptr;
     Records rec{};
     for (int pass = 0; pass < 2; pass++) {
@@ -355,11 +358,13 @@ s2k_status enqueue(s2k_ctx *ctx) {
             tile_rec_off = a.take<uint64_t>(n_tiles + 1);
             tile_goff = a.take<uint64_t>(n_tiles + 1);
         }
-        if (want_runs) {
+        if (want_runs && c.full_runs) {
             run_blk = a.take<uint32_t>(n_runblk + 1);
             run_off = a.take<uint64_t>(n_runblk + 2);
             run_tmp = a.take<uint64_t>(scan_tmp_bytes(n_runblk) / sizeof(uint64_t) + 1);
             read_runs = a.take<uint32_t>(n_reads + 1);
+        } else if (want_runs) {
+            tile_heads = a.take<uint32_t>(n_tiles + 1);
         }
         if (use_desc) {
             d_agg = a.take<unsigned long long>(n_tiles);
@@ -418,10 +423,19 @@ s2k_status enqueue(s2k_ctx *ctx) {
         S2K_TRY(launch_tile_index(c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, st), "tile index kernel");
         Sem sem = c.sem;
         sem.read_runs = nullptr;
+        // HpcSimd: the tail rule needs the run count of the whole read.  Default: the tiles tell each other (Sem::tile_heads, a
+        // word per tile published right after its compaction; a tile in which a read ends that began earlier looks back) -- no
+        // second pass over the bases.  Fall-back (a look-back gave up, S2K_FULL_RUNS): the runs of every read counted first.
+        sem.tile_heads = nullptr;
         if (want_runs) {
-            S2K_TRY(launch_read_run_counts(c.d_bases, c.d_read_off, n_reads, n_bases, run_blk, run_off, run_tmp, read_runs, nullptr, st),
-                    "run count kernels");
-            sem.read_runs = read_runs;
+            if (c.full_runs) {
+                S2K_TRY(launch_read_run_counts(c.d_bases, c.d_read_off, n_reads, n_bases, run_blk, run_off, run_tmp, read_runs, nullptr, st),
+                        "run count kernels");
+                sem.read_runs = read_runs;
+            } else {
+                S2K_TRY(hipMemsetAsync(tile_heads, 0, n_tiles * sizeof(uint32_t), st), "memset tile head words");
+                sem.tile_heads = tile_heads;
+            }
         }
         if (use_desc) {
             Desc dz{};
@@ -535,12 +549,21 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
         if (h->need_legacy && c.desc_run) { // the descriptor path met a tile with more read starts than it lists (reads shorter than
                                             // ~300 bases) or a span that does not fit its records: the whole call takes the legacy path
             c.legacy = true;
+            if (ctx->trace) fprintf(stderr, "[s2k] re-run: the descriptor path met a tile it does not handle -> legacy path\n");
+            s2k_status st = enqueue(ctx);
+            if (st != S2K_OK) return st;
+            continue;
+        }
+        if (h->need_runs && !c.full_runs) { // HpcSimd: a tile waited too long for the word of an earlier one (see enqueue())
+            c.full_runs = true;
+            if (ctx->trace) fprintf(stderr, "[s2k] re-run: a look-back for run heads gave up -> runs of every read counted first\n");
             s2k_status st = enqueue(ctx);
             if (st != S2K_OK) return st;
             continue;
         }
         if (h->pool_overflow) { // record pool (serial) / overflow region (tiled) too small: re-run with the exact size
             c.pool_cap = h->pool_needed + h->pool_needed / 64 + (uint64_t)TILE_BASES + 4096;
+            if (ctx->trace) fprintf(stderr, "[s2k] re-run: record pool too small -> %llu records\n", (unsigned long long)c.pool_cap);
             s2k_status st = enqueue(ctx);
             if (st != S2K_OK) return st;
             continue;
@@ -551,7 +574,10 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
         h->path = c.serial ? 1u : (c.desc_run ? 0u : 2u);
         if (c.sem.dbg_skip & 32) // KNOBS builds: spread of the waves' finishing times in the tiled kernel
         {
-            fprintf(stderr, "[s2k dbg] last wave finished %.1f us after the first\n", (double)(h->dbg_cycles[0][0] - ~h->dbg_cycles[0][1]) * 0.01);
+            fprintf(stderr, "[s2k dbg] last wave finished %.1f us after the first; shader clock under the tiled kernel %.0f MHz (waves alive %.3f ms on average)\n",
+                    (double)(h->dbg_cycles[0][0] - ~h->dbg_cycles[0][1]) * 0.01,
+                    h->dbg_cycles[1][1] ? 100.0 * (double)h->dbg_cycles[1][0] / (double)h->dbg_cycles[1][1] : 0.0,
+                    (double)h->dbg_cycles[1][1] * 1e-5 / (256.0 * 12.0));
 #ifdef S2K_DEBUG_KNOBS
             if (const char *path = getenv("S2K_DEBUG_WAVE_DUMP")) {
                 if (FILE *f = fopen(path, "w")) {
@@ -653,6 +679,8 @@ s2k_ctx *s2k_create(int device, s2k_status *status) {
     memset(ctx->h_counts, 0, sizeof(Counts));
     if (const char *e = getenv("S2K_DESC_CHUNKS")) // tuning / A-B runs: chunks of tiles per call on the descriptor path (1 = no second stream)
         if (atoi(e) >= 1 && atoi(e) <= 64) ctx->desc_chunks = (uint32_t)atoi(e);
+    if (const char *e = getenv("S2K_TRACE")) ctx->trace = atoi(e) != 0;
+    if (const char *e = getenv("S2K_FULL_RUNS")) ctx->force_full_runs = atoi(e) != 0;
     *status = S2K_OK;
     return ctx;
 }
@@ -760,6 +788,7 @@ s2k_status s2k_extract_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64
 #endif
     c.serial = (params->flags & S2K_FLAG_FORCE_SERIAL) || !tiled_supported(c.sem);
     c.legacy = (params->flags & S2K_FLAG_LEGACY_PATH) != 0;
+    c.full_runs = ctx->force_full_runs;
     // The tiled kernel stages tiles with 16 B vector loads, i.e. it needs a 16 B aligned base pointer.  A misaligned
     // stream is first copied to an aligned buffer (one device-to-device pass, ~3 ms per 10 GB) instead of being handed to
     // the read-serial kernels as in round 1 (20-40x slower for the whole call).

@@ -67,7 +67,7 @@ __device__ inline AggF wave_scan_agg(AggF a, int lane, uint32_t K1) {
     }
     return a;
 }
-__device__ inline bool scan_off(const Counts *counts) { return counts->need_legacy || counts->bad_input || counts->pool_overflow; }
+__device__ inline bool scan_off(const Counts *counts) { return counts->need_legacy || counts->need_runs || counts->bad_input || counts->pool_overflow; }
 
 // one wave per 64 entries of a level: what the 64 together do (coalesced loads, log-step scan)
 template <bool PACKED>
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
     if (t >= tile_end) return; // whole waves leave together; no block-level barrier below
     // ---- round trip 1: everything whose address depends on nothing loaded -- the words of this tile and of the 63 before it,
     //      its state, its segment list, and its first 64 records under the assumption that they sit in the tile's own slab
-    const uint32_t off_flags = counts->need_legacy | counts->bad_input | counts->pool_overflow;
+    const uint32_t off_flags = counts->need_legacy | counts->need_runs | counts->bad_input | counts->pool_overflow;
     const unsigned long long agw = t >= (uint64_t)lane ? dz.agg[t - lane] : 0ull; // lane 0: this tile; lane i: tile t - i
     const TileState st = dz.state[t];
     const TileMeta *m = &dz.meta[t];

@@ -65,7 +65,11 @@ struct Sem {
     uint32_t tail_quirk; // drop the final 16-block when #l-mers % 16 == 0 (src/nthash_avx512_32.rs:134-138)
     uint32_t dbg_skip;   // timing ablations only (env S2K_DEBUG_SKIP; results are wrong when set): 1 hash loop, 2 dense phase, 4 hpc compaction
     uint32_t pad_;
-    const uint32_t *read_runs; // HpcSimd on the tiled kernel: number of runs of every read (launch_read_run_counts), else null
+    // HpcSimd on the tiled kernel: its tail rule needs the number of runs of the whole read.  tile_heads (default): every tile
+    // publishes, right after its compaction, how many run heads of the read that continues past its end it holds; a tile in which
+    // such a read ends looks back (HW_* below).  read_runs (the fall-back, launch_read_run_counts): the table of a pre-pass.
+    const uint32_t *read_runs;
+    uint32_t *tile_heads;
 };
 
 struct Counts { // mirrored by s2k_counts (include/s2k.h)
@@ -74,13 +78,18 @@ struct Counts { // mirrored by s2k_counts (include/s2k.h)
     // internal
     uint64_t pool_needed;
     uint32_t pool_overflow, bad_input, km_overflow, mn_overflow; // bad_input: BAD_* bits set by validate_read_off_kernel
-    uint32_t need_legacy, pad2_; // descriptor path: a tile it cannot handle was met (> 30 read starts, a span >= 2^18): the host re-runs the call through the legacy path
+    uint32_t need_legacy, need_runs; // need_runs: HpcSimd: a look-back for the run heads of earlier tiles gave up (bounded polls): the host re-runs the call with the
+                                     // runs of every read counted first.  need_legacy: descriptor path: a tile it cannot handle was met (> 30 read starts, a span >= 2^18): the host re-runs the call through the legacy path
     // fused path: a tile it cannot handle was met (or a look-back timed out): the host re-runs the call unfused
     uint64_t dbg_cycles[64][16]; // S2K_DEBUG_SKIP & 8: shader-clock cycles per phase, summed over waves
 #ifdef S2K_DEBUG_KNOBS
     uint64_t dbg_wave[4096][2];  // S2K_DEBUG_SKIP & 32: per wave {finish time (100 MHz) , XCC_ID << 32 | HW_ID}
 #endif
 };
+
+// word a tile publishes in Sem::tile_heads: run heads of the tile that belong to the read continuing past its end (bits 0-15; the
+// whole tile when HW_PASS: no read starts in it, the read it lies in began before it)
+constexpr uint32_t HW_VALID = 1u << 31, HW_PASS = 1u << 30, HW_COUNT = 0xFFFFu;
 
 // what validate_read_off_kernel found wrong with a caller's device-resident read table (s2k_extract_device trusts nothing)
 enum : uint32_t { BAD_FIRST = 1u, BAD_ORDER = 2u, BAD_END = 4u, BAD_LONG = 8u };

@@ -27,7 +27,7 @@ hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off
                                   uint64_t *pool_cursor, uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt,
                                   Counts *counts, const Desc *desc, uint64_t tile_begin, hipStream_t st) {
     if (n_tiles <= tile_begin || n_reads == 0) return hipSuccess;
-    if (sem.l > (uint32_t)MAX_L_TILED || (sem.hpc && sem.tail_quirk && !sem.read_runs)) return hipErrorInvalidValue;
+    if (sem.l > (uint32_t)MAX_L_TILED || (sem.hpc && sem.tail_quirk && !sem.read_runs && !sem.tile_heads)) return hipErrorInvalidValue;
     if (desc && (desc->k == 0 || desc->k > 32u || !desc->agg || !desc->meta)) return hipErrorInvalidValue;
     switch (sem.l) {
 #define S2K_CASE(LV)                                                                                                   \

@@ -43,7 +43,8 @@
 //    shared overflow region with one atomic.  (One shared cursor for every tile serialised the kernel.)
 //
 // Diagnostics: S2K_DEBUG_SKIP (bit 1 skip hash loop, 2 skip dense phase, 4 skip compaction, 8 per-phase cycle
-// stamps printed by the host -- only in builds made with `make PROFILE=1` --, 16/64 skip stores / re-derivation) and
+// stamps printed by the host -- only in builds made with `make PROFILE=1` --, 16/64 skip stores / re-derivation, 128 skip
+// listing + re-derivation + rounds) and
 // S2K_DEBUG_BLOCKS_PER_CU are timing ablations only -- results are wrong when a skip bit is set.  The library reads
 // these environment variables only when built with `make KNOBS=1` (or PROFILE=1); the shipped build ignores them.
 #pragma once
@@ -602,6 +603,68 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
     raw_e = y_in ? re : he;
 }
 
+// HpcSimd without a second pass over the bases: run heads that the tiles before tile t hold of the read that continues into it.
+// Every tile publishes one word right after its compaction (publish_tile_heads): HW_VALID | count of its run heads that belong
+// to the read continuing past its end, HW_PASS when that is the whole tile (no read starts in it and the read it lies in began
+// earlier).  The sum runs back over PASS tiles to the first tile that is not one, 64 tiles per load.  A word is published early in
+// a tile's life and is looked at late in the life of a later tile, and nothing a tile publishes depends on anything it waits for:
+// no chains, mostly no waiting.  Polls are bounded (a wave that is not resident, CU masking): then need_runs is raised and the
+// host re-runs the call with the runs of every read counted by a pre-pass (s2k_api.hip).
+__device__ __forceinline__ uint32_t lookback_heads(const uint32_t *W, uint64_t t, int lane, Counts *counts, uint32_t early) {
+    uint32_t sum = 0;
+    for (uint64_t tb = t;;) { // tiles tb-1 .. tb-64, lane i looks at tile tb-1-i
+        const bool exists = tb >= 1 + (uint64_t)lane;
+        const uint32_t *p = W + (exists ? tb - 1 - (uint64_t)lane : 0);
+        uint32_t w = HW_VALID; // before tile 0: the chain ends, nothing to add
+        int fs = 64;
+        for (int polls = 0;; polls++) {
+            // (the first look is at what was loaded before the hash loop -- lookback_early --: by now a global round trip old)
+            if (exists) w = (polls == 0 && tb == t) ? early : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t valid = __ballot((w & HW_VALID) != 0u);
+            const uint64_t stop = __ballot((w & HW_VALID) != 0u && (w & HW_PASS) == 0u);
+            fs = stop ? __builtin_ctzll(stop) : 64; // the nearest tile known to end the chain; every tile nearer than it must be known too
+            const uint64_t need = fs >= 63 ? ~0ull : ((2ull << fs) - 1ull);
+            if ((valid & need) == need) break;
+            if (polls >= 4096) { // ~10 ms: hundreds of tile times
+                if (lane == 0) counts->need_runs = 1;
+                return 0;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        const uint32_t mine = (lane <= fs) ? (w & HW_COUNT) : 0u;
+        sum += bcast(wave_incl_scan(mine, lane), 63);
+        if (fs < 64) break;
+        tb -= 64; // (64 PASS tiles in a row: a read of more than half a million bases)
+    }
+    return sum;
+}
+
+// ... and the word itself (HpcSimd only; after hpc_compact: S.hbase / S.fm hold the tile's run heads).  last_start: where the
+// last read that starts in (t0, tile end] starts, if there is one.
+template <class WL>
+__device__ __forceinline__ void publish_tile_heads(uint32_t *W, uint64_t t, const WL &S, uint32_t nh, uint64_t t0, uint32_t tile_len,
+                                                   bool any_start, uint64_t last_start, bool first_begins_here, int lane) {
+    uint32_t word;
+    if (!any_start) {
+        word = HW_VALID | (first_begins_here ? 0u : HW_PASS) | nh; // one read all through (it began at t0, or earlier: PASS)
+    } else if (last_start >= t0 + tile_len) {
+        word = HW_VALID; // a read starts exactly where the tile ends: nothing continues past it
+    } else { // run heads from the last read start on: nh - rank of that (forced) head
+        const uint32_t rel = (uint32_t)(last_start - t0), o = rel / TILE_T, wi = rel % TILE_T;
+        uint32_t c = S.hbase[o];
+        uint32_t f[5];
+#pragma unroll
+        for (int gg = 0; gg < 5; gg++) f[gg] = S.fm[o][gg]; // (all five at once: one LDS round trip, not one per word)
+#pragma unroll
+        for (int gg = 0; gg < 5; gg++) {
+            const int v = (int)wi - 32 * gg; // bits of word gg that lie before the read start
+            c += __popc(f[gg] & (v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u))));
+        }
+        word = HW_VALID | (nh - c);
+    }
+    if (lane == 0) __hip_atomic_store(W + t, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Dense phase of one tile: hit bitmasks -> validated, ordered minimizer records in the tile's slab.  Returns their number
 // and sets `base` (the slab, or a piece of the overflow region).
 //  * DESC = true (default path): 8 bytes per minimizer -- the 32-bit hash and {offset of the l-mer's first base inside the
@@ -617,8 +680,8 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                                                 uint64_t rs0, int lane, const Records &rec, uint64_t *pool_cursor,
                                                 uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem,
                                                 unsigned long long *__restrict__ d_agg, TileMeta *__restrict__ d_meta, uint32_t K1,
-                                                const uint32_t (&caps)[NPC], const uint32_t (&raw)[5], uint64_t *ph,
-                                                uint64_t &stamp) {
+                                                const uint32_t (&caps)[NPC], const uint32_t (&raw)[5], uint32_t lb_early,
+                                                uint64_t *ph, uint64_t &stamp) {
     // (1) read starts that matter for this tile -> hash-space boundaries HB; an l-mer x is invalid iff
     //     some boundary has HB - w <= x <= HB - 1  (w = l-1 raw positions for Regular: the l-mer must end
     //     before the next read, src/lib.rs:215-230; w = l run heads for Hpc: head x+l must exist in the
@@ -643,6 +706,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     {
         uint64_t bpos = bpos0; // read_off[r0 + 1 + lane], fetched ahead; later chunks are loaded here (rare)
         uint64_t chunk_prev = rs0; // start of the read whose end lane 0 holds
+        int32_t hb_carry = 0;      // (HpcSimd) head-space position of the last boundary of the chunk of 64 before
         for (uint32_t c0 = 0;; c0 += 64) { // wave-uniform; one trip unless the tile holds > 63 read starts
             const bool internal = bpos > t0 && bpos < tile_end;
             const bool external = bpos >= tile_end; // entry n_reads (end of stream) always qualifies
@@ -685,8 +749,29 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                 if (sem.tail_quirk) { // HpcSimd (src/nthash_hpc_simd.rs:35-68): same rule on the run count of the whole read
                     pstart = ((uint64_t)__shfl_up((uint32_t)(bpos >> 32), 1) << 32) | __shfl_up((uint32_t)bpos, 1);
                     if (lane == 0) pstart = chunk_prev;
-                    if ((internal || (external && lane == first_ext)) && bpos != ~0ull) {
-                        const uint32_t Rr = sem.read_runs[(uint64_t)r0 + c0 + lane]; // lane holds the end of that read
+                    const bool bnd = (internal || (external && lane == first_ext)) && bpos != ~0ull; // lane holds the end of read r0 + c0 + lane
+                    uint32_t Rr = 0;
+                    if (sem.read_runs) { // fall-back: the table of a pre-pass
+                        if (bnd) Rr = sem.read_runs[(uint64_t)r0 + c0 + lane];
+                    } else {
+                        // The read that ends at boundary i began at boundary i-1 (head-space positions: HB counts the run heads of
+                        // the tile before a read start, the start itself being a forced head), so its run count is HB[i] - HB[i-1];
+                        // the read that ends at the tile's FIRST boundary began at head 0 -- or in an earlier tile: then the tiles
+                        // before this one published how many of its run heads they hold (Sem::tile_heads), and this one looks back.
+                        // Only a boundary the rule can reach from inside the tile matters: an end more than l + 16 run heads past
+                        // the tile (HB is a lower bound then) clears nothing below nh whatever Rr is.
+                        int32_t hprev = (int32_t)__shfl_up((uint32_t)HB, 1);
+                        if (lane == 0) hprev = c0 == 0 ? 0 : hb_carry;
+                        Rr = (uint32_t)(HB - hprev);
+                        const bool began_before = c0 == 0 && !(t0 == 0 || rs0 == t0);
+                        const bool reach = bnd && lane == 0 && began_before && HB - (int32_t)(wclr + 16u) < (int32_t)nh;
+                        if (__ballot(reach)) { // wave-uniform
+                            const uint32_t carried = lookback_heads(sem.tile_heads, t, lane, counts, lb_early);
+                            if (lane == 0) Rr += carried;
+                        }
+                        hb_carry = (int32_t)bcast((uint32_t)HB, 63);
+                    }
+                    if (bnd) {
                         if (bpos - pstart <= (uint64_t)l) {
                             // seq.len() <= l yields nothing (src/lib.rs:97).  Only a read of exactly l distinct bases has a
                             // window that survives the l-1 clear; a shorter one must not reach back into its predecessor.
@@ -848,7 +933,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             d_meta[t].segstart[lane] = (uint16_t)segstart;
             if (lane) d_meta[t].rs16[lane] = S.rs16[lane];
         }
-        if (N == 0 || dropped) {
+        if (N == 0 || dropped || (sem.dbg_skip & 128)) { // (KNOBS builds, 128: everything after the tile's word ablated)
             issue_next(0u, base);
             return 0;
         }
@@ -1094,6 +1179,9 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         tab[256 + c] = make_uint2(rotl32(h, l), rotr32(r, 1));
     }
     __syncthreads(); // the only workgroup barrier; waves are independent from here on
+#ifdef S2K_DEBUG_KNOBS
+    const uint64_t dbg_mt0 = __builtin_amdgcn_s_memtime(), dbg_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     WL &S = *reinterpret_cast<WL *>(smem + TABLE_BYTES + (size_t)w * sizeof(WL));
     uint8_t *D = S.buf + HS_OFF;
     const uint64_t n_waves = (uint64_t)gridDim.x * TW;
@@ -1170,7 +1258,11 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     // dyn0 + g, dyn0 + g + TILE_CURSORS, ... (pool_cursor[16 + 16 g], zeroed by the host before the launch).
     uint64_t tn = t + n_waves, tnn = t + 2 * n_waves;
     const uint64_t dyn0 = tile_begin + 3 * n_waves;
-    const uint32_t cur_g = (uint32_t)((blockIdx.x * TW + w) % TILE_CURSORS);
+    // Which cursor a wave draws from must not depend on its place in the block alone: the SIMD's arbiter serves its oldest wave
+    // first, so waves in the same slot of every block run at the same (un)favourable speed, and a cursor served by slow waves
+    // only is still dealing when the others have run dry (TW = 16: 16 b + w mod 64 keeps w -- the last wave finished 2.7 ms
+    // after the first).  The second term walks the wave index through the cursors' residues as the blocks go by.
+    const uint32_t cur_g = (uint32_t)((blockIdx.x * TW + w + blockIdx.x / (TILE_CURSORS / 4)) % TILE_CURSORS);
     unsigned int *const cursors = (unsigned int *)(pool_cursor + 16); // 32-bit draws (a 64-bit result's dead upper half would be
                                                                        // reused early and pull a vmcnt(0) in front of the compaction); cursor g = word 32 g
     // (A wave stays with its cursor: when that runs dry the wave is done.  Round 2 let it move on to another cursor that was not;
@@ -1182,6 +1274,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         r1n = tile_read0[tn + 1];
     }
 
+    uint32_t prio_iter = 0;
     for (; t < n_tiles;) {
         // A dozen values derived from the lane index (64-bit zero-extensions, 16 x lane offsets, masks) are loop-invariant; LLVM
         // hoists them out of this loop and then holds -- or spills -- them across the hash loop, where the register pressure
@@ -1189,6 +1282,17 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         // instructions each where they are used.
         lane = lane0;
         asm volatile("" : "+v"(lane));
+        if (sem.tile_heads) {
+            // HpcSimd, look-back for run heads (lookback_heads): the SIMD's arbiter serves its oldest wave first, so the three waves of
+            // a SIMD run at lastingly different speeds, and a tile whose predecessor sits on a slower wave waits for that wave's
+            // word.  Rotating the issue priority tile by tile evens the speeds out: 8.05 -> 7.60 ms per 10 Gbp (other modes: no
+            // gain, not done).
+            switch ((prio_iter++ + (uint32_t)(w >> 2)) % 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(2); break;
+            }
+        }
         const uint64_t t0 = t * (uint64_t)TILE_BASES;
         const uint64_t rem = n_bases - t0;
         const uint32_t avail = rem > (uint64_t)(TILE_BASES + 128) ? (uint32_t)(TILE_BASES + 128) : (uint32_t)rem;
@@ -1262,6 +1366,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         S2K_STAMP(0); // staging
 
         uint32_t nh = tile_len; // number of hash positions owned by this tile
+        uint32_t lb_early = 0;  // (HpcSimd) early look at the words of the tiles before this one, see below
         uint32_t halo_n = 0;
         int np = 9;
         if constexpr (HPC) {
@@ -1270,6 +1375,22 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
                 nh = hpc_compact(D, S, bases, read_off, n_reads, n_bases, t0, tile_len, cr0, cr1, l, lane, halo_n, bpos0,
                                  cprev, t0 == 0 || rs0 == t0, sem, ph, stamp);
 #endif
+            if (sem.tile_heads) { // HpcSimd: tell later tiles how many run heads of the read that continues past this tile it holds
+                const uint32_t ns = cr1 - cr0; // read starts in (t0, tile end]; bpos0 of lane i = start of read r0 + 1 + i
+                uint64_t last_start = 0;
+                if (ns) {
+                    if (ns <= 64)
+                        last_start = ((uint64_t)bcast((uint32_t)(bpos0 >> 32), (int)ns - 1) << 32) | bcast((uint32_t)bpos0, (int)ns - 1);
+                    else
+                        last_start = read_off[cr1]; // (hundreds of reads in one tile)
+                }
+                publish_tile_heads(sem.tile_heads, t, S, nh, t0, tile_len, ns != 0, last_start, t0 == 0 || rs0 == t0, lane);
+                // ... and take a first look at the words of the 64 tiles before this one: the tiles next to it are processed at
+                // about the same time and have mostly published by now; the load has the hash loop to come back (it is waited
+                // for with the other loads right after it), and the dense phase only polls when that look was too early.
+                if (!(t0 == 0 || rs0 == t0) && t >= 1 + (uint64_t)lane)
+                    lb_early = __hip_atomic_load(sem.tile_heads + (t - 1 - (uint64_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             int need = (int)((nh + 1023) >> 10);
             np = need <= 1 ? 1 : need <= 3 ? 3 : need <= 5 ? 5 : need <= 7 ? 7 : 9;
         }
@@ -1335,7 +1456,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
             if (!(sem.dbg_skip & 2))
                 N = dense_phase<L, HPC, DESC>(issue_once, S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1,
                                            bpos0, rs0, lane_d, rec, pool_cursor, mn_cnt, counts, base, sem, d_agg, d_meta, K1,
-                                           caps, raw, ph, stamp);
+                                           caps, raw, lb_early, ph, stamp);
 #endif
             S2K_STAMP(5); // rounds
         }
@@ -1363,6 +1484,9 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         atomicMax((unsigned long long *)&counts->dbg_cycles[0][0], now);
         atomicMax((unsigned long long *)&counts->dbg_cycles[0][1], ~now);
+        // shader clock under this kernel's load: s_memtime counts shader cycles, s_memrealtime the constant 100 MHz clock
+        atomicAdd((unsigned long long *)&counts->dbg_cycles[1][0], (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_mt0));
+        atomicAdd((unsigned long long *)&counts->dbg_cycles[1][1], (unsigned long long)(now - dbg_rt0));
         const uint32_t wid = blockIdx.x * TW + w;
         if (wid < 4096) {
             counts->dbg_wave[wid][0] = now;

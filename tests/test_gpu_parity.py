@@ -837,6 +837,88 @@ print(h.hexdigest())
     assert int(outs[""][0].split()[1]) > 1_000_000  # ~500 Mbp: 54 000 tiles, several chunks by default
 
 
+def test_hpcsimd_run_counts_by_lookback(oracle):
+    """HpcSimd on the tiled kernel without a second pass over the bases: the tail rule needs the run count of the whole read, and
+    the tiles tell each other (a word per tile, published after its compaction; the tile in which a read ends looks back), also
+    across the chunks of the two-stream pipeline.  (a) reads whose run count triggers the rule (R = l - 1 + 16 m), several tiles
+    long, across every chunk boundary; (b) reads whose last 40 run heads span 25 kbp across a chunk boundary (the end of the read is
+    within the rule's reach of a tile but 2.7 tiles away in bytes); (c) = (a) with S2K_FULL_RUNS=1: the fall-back that counts
+    the runs of every read in a pre-pass (taken when a look-back gives up).  No case may need a re-run."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from s2k_loader import import_package
+from gpu_util import compare
+from oracle import s2k_oracle
+pkg = import_package()
+eng = pkg.Engine(0)
+oracle = s2k_oracle.get()
+rng = np.random.default_rng(int(sys.argv[1]))
+l = 31
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+def from_runs(nruns, reps=None):
+    letters = rng.integers(0, 4, size=nruns)
+    letters[1:] = (letters[:-1] + 1 + rng.integers(0, 3, size=nruns - 1)) %% 4
+    if reps is None:
+        reps = rng.choice([1, 2, 3, 5, 9], size=nruns, p=[0.6, 0.2, 0.1, 0.07, 0.03])
+    return np.repeat(ACGT[letters], reps).tobytes()
+TILE = 9216
+reads = []
+if sys.argv[2] == "a":
+    total = 0
+    while total < 14 * 64 * TILE:  # > 13 chunks of 64 tiles
+        m = int(rng.integers(200, 2500))
+        r = from_runs(l - 1 + 16 * m if rng.random() < 0.7 else int(rng.integers(40, 30000)))
+        reads.append(r); total += len(r)
+else:
+    # chunk boundaries of a forced 13-chunk call over exactly 13 * 64 tiles: tile 64 c
+    total_tiles = 13 * 64
+    pos = 0
+    for c in range(1, 13):
+        b = 64 * c * TILE
+        fill = from_runs(l - 1 + 16 * 40)
+        while pos + len(fill) + 30000 < b - 400:  # ordinary rule-triggering reads up to just before the boundary
+            reads.append(fill); pos += len(fill); fill = from_runs(l - 1 + 16 * int(rng.integers(30, 300)))
+        # one read: R = l - 1 + 16 m runs; its last 40 runs start ~100 bytes before the boundary, the first of them 25 kbp long
+        m = 4
+        R = l - 1 + 16 * m
+        reps = rng.choice([1, 2, 3], size=R)
+        head_len = int(reps[: R - 40].sum())
+        start = b - 100 - head_len
+        pad = start - pos
+        assert pad > l + 2
+        reads.append(from_runs(max(pad // 2, 40), reps=None)[:pad]); pos += len(reads[-1])
+        if len(reads[-1]) < pad:
+            reads.append(b"A" * (pad - len(reads[-1]))); pos += len(reads[-1])
+        reps[R - 40] = 25000
+        r = from_runs(R, reps=reps)
+        reads.append(r); pos += len(r)
+    tail = total_tiles * TILE - pos
+    assert tail > 0
+    while tail > 0:
+        r = from_runs(l - 1 + 16 * 20)[:tail]
+        reads.append(r); tail -= len(r)
+for d in (0.5, 0.02):
+    compare(eng, oracle, reads, l, 4, d, pkg.HashMode.HpcSimd, expect_path=0, tag="hpcsimd-chunked-" + sys.argv[2])
+print("ok", len(reads), sum(map(len, reads)))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    for case, seed, full in (("a", "5", False), ("b", "6", False), ("a", "5", True)):
+        env = dict(os.environ)
+        env["S2K_DESC_CHUNKS"] = "13"
+        env["S2K_TRACE"] = "1"
+        env.pop("S2K_FULL_RUNS", None)
+        if full:
+            env["S2K_FULL_RUNS"] = "1"
+        p = subprocess.run([sys.executable, "-c", code, seed, case], capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, (case, full, p.stdout[-1000:], p.stderr[-3000:])
+        assert p.stdout.strip().startswith("ok"), p.stdout
+        assert "re-run" not in p.stderr, (case, full, p.stderr[-2000:])
+
+
 def test_minimizer_iterator_facades(eng, oracle, ecoli):
     """The crate's minimizer iterators (re-exported at src/lib.rs:6-13) as Python classes over S2K_FLAG_WANT_MINIMIZERS, against
     the oracle's minimizers in all four modes: NtHashHPCIterator yields (start, end, hash) (src/nthash_hpc.rs:193),
