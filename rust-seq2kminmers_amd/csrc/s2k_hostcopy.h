@@ -60,7 +60,7 @@ public:
     // quality strings ...) is sent as it is.  SURVEY.md 8f-1: "host-side 2-bit packing to cut PCIe bytes 4x".
     hipError_t h2d_packed(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);
     // same for a source that is produced piecewise (a file: FASTA text is DNA with ~0.1-2 % other bytes, which travel as
-    // exceptions); *packed_any tells whether any chunk went packed (FASTQ never does: the caller stops asking)
+    // exceptions); *packed_any tells whether packing is worth asking for again: false when no chunk packed, or when two chunks in a row did not (FASTQ, soft-masked or N-rich text) and the rest of the call went as it is
     hipError_t h2d_packed_fill(void *dst_dev, size_t bytes, hipStream_t s, const std::function<bool(char *, size_t, size_t)> &fill,
                                bool *packed_any);
     // device -> pageable host, ordered after the work already queued on `s`.  On return `dst` is complete.

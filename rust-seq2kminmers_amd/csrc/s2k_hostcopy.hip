@@ -292,7 +292,14 @@ hipError_t HostStager::packed_impl(void *dst_dev, const uint8_t *src, const std:
     for (int i = 0; i < kSlots; i++)
         if (!dpack_[i] && (e = hipMalloc((void **)&dpack_[i], kChunk)) != hipSuccess) return e;
     size_t off = 0;
+    int overflowed_in_a_row = 0; // chunks that did not pack (soft-masked or N-rich text, FASTQ): each was read and scanned in vain
     for (int i = 0; off < bytes; i++) {
+        if (overflowed_in_a_row >= 2) { // stop trying: the rest goes as it is, and the caller is told not to ask again
+            if (packed_any) *packed_any = false;
+            if (src) return h2d((char *)dst_dev + off, src + off, bytes - off, s);
+            const size_t base = off;
+            return h2d_fill((char *)dst_dev + off, bytes - off, s, [&](char *d, size_t o, size_t len) { return (*fill)(d, base + o, len); });
+        }
         const int slot = i % kSlots;
         const size_t n = bytes - off < kSrc ? bytes - off : kSrc;
         if ((e = hipEventSynchronize(ev_[slot])) != hipSuccess) return e;
@@ -329,8 +336,10 @@ hipError_t HostStager::packed_impl(void *dst_dev, const uint8_t *src, const std:
             }
             if (e != hipSuccess) return e;
             off += n;
+            overflowed_in_a_row++;
             continue;
         }
+        overflowed_in_a_row = 0;
         if (packed_any) *packed_any = true;
         // gather the slices' exception lists behind the packed bytes (few entries; one thread)
         size_t n_exc = 0;
