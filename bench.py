@@ -328,6 +328,17 @@ def main():
                       "kernel_ms": round(min_ms2, 3), "kminmer_kernel_ms": round(km_ms2, 3), "pipeline_ms": round(pipe_ms2, 3),
                       "roofline_frac": round(alg2 / (pipe_ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
+        # the two compatibility modes (result semantics of the reference's AVX-512 iterators, src/nthash_avx512_32.rs /
+        # src/nthash_hpc_simd.rs) on the same kernels: HpcSimd gets the run count of a read from the tiles themselves, no pre-pass
+        compat = {}
+        for nm, hm in (("simd", pkg.HashMode.Simd), ("hpcsimd", pkg.HashMode.HpcSimd)):
+            s3 = max(2, args.steps // 4)
+            dt3, counts3, _, _, pipe_ms3, _ = timed(hm, s3, 1)
+            assert counts3["path"] == (2 if args.legacy_path else 0)
+            tot3 = sharding.allreduce_counts(counts3, dist, red_dev)
+            compat[nm] = {"value": round(tot3["n_bases"] * s3 / dt3 / 1e9, 2), "unit": "Gbp/s", "pipeline_ms": round(pipe_ms3, 3), "kminmers": int(tot3["n_kminmers"])}
+        other_line["compat_modes"] = compat
+
     # whole-job counts: the only collective on this path (RCCL all-reduce of a few words)
     tot = sharding.allreduce_counts(counts, dist, red_dev)
     tot_bases, tot_min, tot_km = tot["n_bases"], tot["n_minimizers"], tot["n_kminmers"]

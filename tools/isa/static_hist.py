@@ -5,9 +5,9 @@ Instructions of inlined helpers (lines < 172 of s2k_tile_impl.h, or other files)
 import re, sys, collections
 path, kern = sys.argv[1], sys.argv[2]
 per_line = '--lines' in sys.argv
-regions = [(172, 325, 'hash'), (357, 536, 'compact'), (538, 593, 'rawpos'), (595, 745, 'dense.boundaries'),
-           (746, 795, 'dense.count'), (796, 850, 'dense.rederive'), (851, 882, 'dense.list'), (883, 912, 'dense.jobs'),
-           (913, 999, 'dense.rounds'), (1000, 1400, 'kernel')]
+regions = [(172, 335, 'hash'), (366, 540, 'compact'), (541, 611, 'rawpos'), (612, 674, 'hpcsimd.lookback'), (675, 850, 'dense.boundaries'),
+           (851, 900, 'dense.count'), (901, 945, 'dense.segments+word'), (946, 1005, 'dense.rederive'), (1006, 1030, 'dense.list'),
+           (1031, 1060, 'dense.jobs'), (1061, 1158, 'dense.rounds'), (1159, 1500, 'kernel')]
 def region(l):
     for a, b, n in regions:
         if a <= l <= b: return n
