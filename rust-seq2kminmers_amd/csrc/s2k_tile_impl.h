@@ -610,8 +610,9 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
 // a tile's life and is looked at late in the life of a later tile, and nothing a tile publishes depends on anything it waits for:
 // no chains, mostly no waiting.  Polls are bounded (a wave that is not resident, CU masking): then need_runs is raised and the
 // host re-runs the call with the runs of every read counted by a pre-pass (s2k_api.hip).
-__device__ __forceinline__ uint32_t lookback_heads(const uint32_t *W, uint64_t t, int lane, Counts *counts, uint32_t early) {
+__device__ __forceinline__ uint32_t lookback_heads(const uint32_t *W, uint64_t t, int lane, Counts *counts, uint32_t early, bool &dead) {
     uint32_t sum = 0;
+    if (dead) return 0; // this wave (or, at its start, anybody: need_runs) has given up once: the call is re-run anyway, do not wait again
     for (uint64_t tb = t;;) { // tiles tb-1 .. tb-64, lane i looks at tile tb-1-i
         const bool exists = tb >= 1 + (uint64_t)lane;
         const uint32_t *p = W + (exists ? tb - 1 - (uint64_t)lane : 0);
@@ -627,6 +628,7 @@ __device__ __forceinline__ uint32_t lookback_heads(const uint32_t *W, uint64_t t
             if ((valid & need) == need) break;
             if (polls >= 4096) { // ~10 ms: hundreds of tile times
                 if (lane == 0) counts->need_runs = 1;
+                dead = true;
                 return 0;
             }
             __builtin_amdgcn_s_sleep(16);
@@ -681,7 +683,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                                                 uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem,
                                                 unsigned long long *__restrict__ d_agg, TileMeta *__restrict__ d_meta, uint32_t K1,
                                                 const uint32_t (&caps)[NPC], const uint32_t (&raw)[5], uint32_t lb_early,
-                                                uint64_t *ph, uint64_t &stamp) {
+                                                bool &lb_dead, uint64_t *ph, uint64_t &stamp) {
     // (1) read starts that matter for this tile -> hash-space boundaries HB; an l-mer x is invalid iff
     //     some boundary has HB - w <= x <= HB - 1  (w = l-1 raw positions for Regular: the l-mer must end
     //     before the next read, src/lib.rs:215-230; w = l run heads for Hpc: head x+l must exist in the
@@ -766,7 +768,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                         const bool began_before = c0 == 0 && !(t0 == 0 || rs0 == t0);
                         const bool reach = bnd && lane == 0 && began_before && HB - (int32_t)(wclr + 16u) < (int32_t)nh;
                         if (__ballot(reach)) { // wave-uniform
-                            const uint32_t carried = lookback_heads(sem.tile_heads, t, lane, counts, lb_early);
+                            const uint32_t carried = lookback_heads(sem.tile_heads, t, lane, counts, lb_early, lb_dead);
                             if (lane == 0) Rr += carried;
                         }
                         hb_carry = (int32_t)bcast((uint32_t)HB, 63);
@@ -1275,6 +1277,9 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     }
 
     uint32_t prio_iter = 0;
+    // HpcSimd look-back (lookback_heads): a wave that has waited in vain once does not wait again -- nor does any wave once the
+    // call is known to be run again (need_runs; e.g. the minimizer kernel of a later chunk)
+    bool lb_dead = sem.tile_heads != nullptr && __builtin_amdgcn_readfirstlane((int)counts->need_runs) != 0;
     for (; t < n_tiles;) {
         // A dozen values derived from the lane index (64-bit zero-extensions, 16 x lane offsets, masks) are loop-invariant; LLVM
         // hoists them out of this loop and then holds -- or spills -- them across the hash loop, where the register pressure
@@ -1456,7 +1461,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
             if (!(sem.dbg_skip & 2))
                 N = dense_phase<L, HPC, DESC>(issue_once, S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1,
                                            bpos0, rs0, lane_d, rec, pool_cursor, mn_cnt, counts, base, sem, d_agg, d_meta, K1,
-                                           caps, raw, lb_early, ph, stamp);
+                                           caps, raw, lb_early, lb_dead, ph, stamp);
 #endif
             S2K_STAMP(5); // rounds
         }

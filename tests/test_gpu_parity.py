@@ -919,6 +919,47 @@ print("ok", len(reads), sum(map(len, reads)))
         assert "re-run" not in p.stderr, (case, full, p.stderr[-2000:])
 
 
+def test_hpcsimd_lookback_two_processes_one_gpu():
+    """Two processes share the GPU while both run HpcSimd: neither minimizer kernel has all its waves resident, so a tile can wait
+    for the word of a tile whose wave has not started -- the look-back must give up after a bounded wait and the call must be run
+    again with the runs counted first, not hang and not answer wrongly.  Each process compares the look-back engine with one
+    created under S2K_FULL_RUNS=1 (pre-pass) on the same input, byte for byte, several calls in a row."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, os, numpy as np
+sys.path.insert(0, %r)
+from s2k_loader import import_package
+pkg = import_package()
+rng = np.random.default_rng(int(sys.argv[1]))
+lens = rng.integers(2000, 40000, size=14000)
+off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(off[-1]))]
+bases = np.repeat(bases, rng.choice([1, 1, 1, 2, 4], size=len(bases)))[: int(off[-1])].copy()
+eng = pkg.Engine(0)
+os.environ["S2K_FULL_RUNS"] = "1"
+eng_pre = pkg.Engine(0)
+del os.environ["S2K_FULL_RUNS"]
+ref = eng_pre.extract(bases, off, 31, 10, 0.02, pkg.HashMode.HpcSimd, want_minimizers=True)
+for it in range(6):
+    got = eng.extract(bases, off, 31, 10, 0.02, pkg.HashMode.HpcSimd, want_minimizers=True)
+    assert got["n"] == ref["n"] and got["n_minimizers"] == ref["n_minimizers"], (it, got["n"], ref["n"])
+    for f in ("km_off", "hash", "start", "end", "rev", "mn_off", "mn_j", "mn_jend", "mn_hash"):
+        assert (got[f] == ref[f]).all(), (it, f)
+print("ok", ref["n"])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["S2K_TRACE"] = "1"
+    env.pop("S2K_FULL_RUNS", None)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for seed in (41, 42)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (so[-500:], se[-3000:])
+        assert so.strip().startswith("ok"), so
+    print("re-runs seen:", sum(se.count("re-run") for _, se in outs))
+
+
 def test_minimizer_iterator_facades(eng, oracle, ecoli):
     """The crate's minimizer iterators (re-exported at src/lib.rs:6-13) as Python classes over S2K_FLAG_WANT_MINIMIZERS, against
     the oracle's minimizers in all four modes: NtHashHPCIterator yields (start, end, hash) (src/nthash_hpc.rs:193),
