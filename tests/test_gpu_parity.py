@@ -254,8 +254,8 @@ def test_simd_tail_rule_across_tiles(eng, oracle):
 
 
 def test_hpcsimd_tail_rule_across_tiles(eng, oracle):
-    """HpcSimd on the tiled kernel: the tail rule applies to the number of RUNS of the whole read (counted by a
-    pre-pass), the end position is the start of the last run, the last HPC l-mer is kept.  Reads are built from runs so
+    """HpcSimd on the tiled kernel: the tail rule applies to the number of RUNS of the whole read (told from tile to tile,
+    DESIGN.md 3.1a), the end position is the start of the last run, the last HPC l-mer is kept.  Reads are built from runs so
     that the run count is controlled: R = l - 1 + 16 m triggers the rule; lengths up to several tiles."""
     rng = np.random.default_rng(22)
 
