@@ -768,8 +768,26 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                         const bool began_before = c0 == 0 && !(t0 == 0 || rs0 == t0);
                         const bool reach = bnd && lane == 0 && began_before && HB - (int32_t)(wclr + 16u) < (int32_t)nh;
                         if (__ballot(reach)) { // wave-uniform
-                            const uint32_t carried = lookback_heads(sem.tile_heads, t, lane, counts, lb_early, lb_dead);
-                            if (lane == 0) Rr += carried;
+                            // ... and only if the tile HAS a hit among the positions the rule would take away beyond the plain clear,
+                            // [HB - w - 16, HB - w - 1]: three times in four it has none, and the count does not matter
+                            const int32_t hb0 = (int32_t)bcast((uint32_t)HB, 0);
+                            const int lo = hb0 - (int)wclr - 16 - (int)(Tq * lane), hi = hb0 - (int)wclr - 1 - (int)(Tq * lane); // lane-local, inclusive
+                            uint32_t inwin = 0;
+                            if (hi >= 0 && lo < (int)Tq) {
+#pragma unroll
+                                for (int d = 0; d < 5; d++) {
+                                    const int a = lo - 32 * d, bnd2 = hi - 32 * d;
+                                    if (bnd2 >= 0 && a < 32) {
+                                        const uint32_t m_hi = bnd2 >= 31 ? 0xFFFFFFFFu : ((2u << bnd2) - 1u);
+                                        const uint32_t m_lo = a <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << a);
+                                        inwin |= vm[d] & m_hi & m_lo;
+                                    }
+                                }
+                            }
+                            if (__ballot(inwin != 0u)) {
+                                const uint32_t carried = lookback_heads(sem.tile_heads, t, lane, counts, lb_early, lb_dead);
+                                if (lane == 0) Rr += carried;
+                            }
                         }
                         hb_carry = (int32_t)bcast((uint32_t)HB, 63);
                     }
