@@ -30,15 +30,20 @@
 //    popcounts + one DPP scan give every lane its output offset; lanes list their hits (16-bit entries in LDS); the
 //    ~14 % of hits that were not the last of their piece are queued and re-derived from their l bytes, four lanes per
 //    hit, BEFORE the rounds (from then on the tile's bytes are dead and the next tile is loaded into the same buffer);
-//    then one lane per hit finds its read among the read starts kept in LDS, back-maps positions and writes the record
-//    with coalesced stores.  No global LOAD sits in that loop: one would make the compiler drain every outstanding
-//    store of the previous round.
+//    then one lane per hit back-maps its position and writes ONE word per minimizer: {offset of the l-mer's first base in the
+//    tile : 14, span to its last base : 18}.  The tile also leaves a 64-bit word (what it does to the running pair "k-min-mers
+//    so far, minimizers of the read that continues") and its list of read segments; k-min-mers are made from these by
+//    s2k_desc.hip (descriptor path).  The legacy path (k > 32, > 30 read starts per tile) instead finds each hit's read among
+//    the read starts kept in LDS and writes 16-byte records for s2k_kminmer.hip.  No global LOAD sits in the round loop: one
+//    would make the compiler drain every outstanding store of the previous round.
 //  * Hpc mode first compacts the tile's run heads in place in LDS (SWAR byte compares -> v_dot4 nibbles -> per-lane
 //    flag masks in natural bit order, popcounts, one wave scan, overwrite-style byte stores), appends the l run heads
 //    that follow the tile (first from the staged look-ahead, then by a loop over the stream, so arbitrarily long
 //    homopolymers are fine), and then runs the same hash loop over the compacted bytes.  Raw positions are recovered
 //    for hits only, from the per-lane flag masks (owner-lane hint table + select-nth-bit).  Read starts are forced run
 //    heads: they are OR-ed into the flag masks; the staged bytes are never modified, so ANY byte value is fine.
+//  * HpcSimd result semantics need the run count of the whole read where it ends: every tile publishes how many run heads of
+//    the read continuing past its end it holds, the tile in which the read ends looks back (lookback_heads) -- no second pass.
 //  * Records go to a fixed per-tile slab (mean + 6 sigma); only a tile with more hits takes space from a
 //    shared overflow region with one atomic.  (One shared cursor for every tile serialised the kernel.)
 //
@@ -328,8 +333,9 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
 // same number of tiles) the first-launched wave of each SIMD ran out of tiles 3.7 ms before the last-launched one, and the
 // SIMDs spent the last third of the kernel with two, then one wave (tools/tail_spread.sh, profiles/r02_zz_tail_spread.txt).
 // A wave takes its first three tiles statically (the software pipeline is three deep) and every later one from one of
-// TILE_CURSORS cursors in global memory, two iterations before it processes it; when its cursor runs dry it moves on to
-// one that is not.  (ONE cursor for all waves was measured first: 1.085 M atomics on one address are serialised at ~12 ns
+// TILE_CURSORS cursors in global memory, two iterations before it processes it; when its cursor runs dry the wave is done
+// (moving on to a cursor that is not was measured again in round 3: -1 %).  Which cursor a wave draws from is decorrelated from its
+// slot in the block (see cur_g).  (ONE cursor for all waves was measured first: 1.085 M atomics on one address are serialised at ~12 ns
 // each and the kernel took 13.2 ms; 64 addresses, 128 B apart, are not a bottleneck.)
 // (s_setprio per phase -- dense phase high and hash loop low, and the reverse -- moved the kernel by <= 1 % either way: not used.)
 
