@@ -380,6 +380,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
         rec.capacity = rec_total;
         rec.slab_cap = c.serial ? 0 : c.slab_cap;
         rec.ovf_base = c.serial ? 0 : n_tiles * c.slab_cap;
+        rec.ovf_cursor = (unsigned long long *)pool_cursor; // word 0 of the first block of cursors (all zeroed below)
         if (pass == 0) {
             S2K_TRY(ctx->ws.ensure(a.off + 256), "workspace allocation");
             a.base = (char *)ctx->ws.p;

@@ -122,6 +122,9 @@ struct Records { // SoA pool of minimizer records written by the minimizer kerne
     // with one atomic.  A single shared cursor for every tile serialises the whole kernel (~88 atomics
     // per microsecond on one address = 12 ms for 1.1 M tiles).
     uint64_t slab_cap, ovf_base;
+    // ... ONE cursor for the whole call: the chunks of the two-stream pipeline each have their own tile cursors, but the overflow
+    // region is shared -- and the k-min-mer kernel of a chunk reads its records while the minimizer kernel of the next writes
+    unsigned long long *ovf_cursor;
 };
 
 // ---- descriptor path (the default for k <= 32): tile-relative records + one descriptor word per tile -----------------------------

@@ -883,7 +883,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     bool dropped = false; // no room for the tile's records: the host re-runs with a larger pool
     if (N > rec.slab_cap) { // rare: more hits than the per-tile slab holds
         uint64_t got = 0;
-        if (lane == 0) got = atomicAdd((unsigned long long *)pool_cursor, (unsigned long long)N);
+        if (lane == 0) got = atomicAdd(rec.ovf_cursor, (unsigned long long)N);
         got = ((uint64_t)bcast((uint32_t)(got >> 32), 0) << 32) | bcast((uint32_t)got, 0);
         base = rec.ovf_base + got;
         if (base + N > rec.capacity) { // overflow region exhausted: the host re-runs with pool_needed

@@ -822,6 +822,18 @@ for mode in (0, 1):
     for f in ("km_off", "hash", "start", "end", "rev", "mn_off", "mn_j", "mn_jend", "mn_hash"):
         h.update(r[f].tobytes())
     print(mode, r["n"], r["n_minimizers"])
+# low-complexity sequence: tiles with far more minimizers than their slab holds take space from the overflow region, which the chunks
+# share (one cursor for the whole call: the k-min-mer kernel of a chunk reads its records while the next chunk's are written)
+lens = rng.integers(20000, 400000, size=12)
+off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(off[-1]))]
+bases = np.repeat(bases, rng.choice([1, 1, 3, 60, 700], size=len(bases)))[: int(off[-1])].copy()
+for mode, k, d in ((0, 1, 0.1), (0, 10, 0.05), (1, 3, 0.5)):
+    r = eng.extract(bases, off, 15, k, d, mode, want_minimizers=True)
+    assert r["counts"]["path"] == 0
+    for f in ("km_off", "hash", "start", "end", "rev", "mn_off", "mn_j", "mn_jend", "mn_hash"):
+        h.update(r[f].tobytes())
+    print("lowc", mode, k, r["n"], r["n_minimizers"])
 print(h.hexdigest())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
