@@ -10,18 +10,29 @@ from oracle import s2k_oracle as so
 HM = pkg.HashMode
 seed, iters = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed); T = 9216
-eng = pkg.Engine(0); oracle = so.get()
+# FUZZ_CHUNKS="1,2,3,7": one engine per forced chunk count of the two-stream pipeline (S2K_DESC_CHUNKS is read when a context is
+# created), one of them drawn per batch; unset: one engine with the library's default
+engines = []
+for ck in [c for c in os.environ.get("FUZZ_CHUNKS", "").split(",") if c]:
+    os.environ["S2K_DESC_CHUNKS"] = ck
+    engines.append(pkg.Engine(0))
+if not engines: engines.append(pkg.Engine(0))
+oracle = so.get()
 bad = 0; t0 = time.time()
 for it in range(iters):
     l = int(rng.choice([31, 31, 31, 4, 5, 12, 15, 16, 20, 21, 31, 32, 33, 40, 63, 64, 65, 80]))
     k = int(rng.choice([1, 2, 3, 5, 10, 17, 40]))
     d = float(rng.choice([0.001, 0.003, 0.01, 0.02, 0.1, 0.5, 1.0]))
     shape = int(rng.integers(0, 5))
+    eng = engines[int(rng.integers(0, len(engines)))]
+    if len(engines) > 1 and rng.random() < 0.15: shape = 5
     lens = []
     if shape == 0:      # many tiny reads: > 30 read starts per tile (the per-hit read-table search)
         lens = [int(rng.integers(0, 3 * l + 8)) for _ in range(int(rng.integers(200, 3000)))]
     elif shape == 1:    # a few long reads
         lens = [int(rng.integers(20000, 400000)) for _ in range(int(rng.integers(1, 6)))]
+    elif shape == 5:    # a batch of several hundred tiles: every forced chunk count really chunks (>= 64 tiles per chunk)
+        lens = [int(rng.integers(500, 60000)) for _ in range(int(rng.integers(100, 400)))]
     else:
         for _ in range(int(rng.integers(1, 80))):
             kind = rng.integers(0, 6)
