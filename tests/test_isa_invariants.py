@@ -12,3 +12,28 @@ def test_counted_vmcnt_wait_matches_the_emitted_stores():
     r = subprocess.run(["make", "-C", csrc, "-j", "2", "isa-check"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "vector-memory ops per round" in r.stdout
+
+
+def test_tiled_kernels_fit_three_waves_per_simd_without_scratch():
+    """The persistent tile kernel runs one block of 12 waves per CU = three per SIMD: 512 VGPRs / 3 = 168 per wave at most, and no
+    scratch (a spill in the hash loop costs more than anything else in it).  Round 3 lost 20-55 VGPRs to loop-invariant lane
+    arithmetic hoisted across the hash loop; this keeps that from coming back unnoticed.  Also: the compile-time-l
+    kernels use gfx950's three-input bit operation in the hash loop (2 x 144 positions x 2 strands and more)."""
+    import re
+
+    csrc = os.path.join(ROOT, "rust-seq2kminmers_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "-j", "2", "isa/s2k_tile_L31.s", "isa/s2k_tile_L0.s"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    seen = 0
+    for name in ("s2k_tile_L31.s", "s2k_tile_L0.s"):
+        text = open(os.path.join(csrc, "isa", name)).read()
+        for m in re.finditer(r"\.name:\s+(\S*tile_minimizer_kernel\S*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text):
+            kern, vgprs, spills = m.group(1), int(m.group(2)), int(m.group(3))
+            seen += 1
+            assert vgprs <= 168, (name, kern, vgprs)
+            assert spills == 0, (name, kern, spills)
+        for m in re.finditer(r"; ScratchSize: (\d+)", text):
+            assert int(m.group(1)) == 0, (name, "scratch", m.group(1))
+        if name == "s2k_tile_L31.s":
+            assert text.count("bitop3:0x96") >= 4 * 2 * 144, "v_bitop3_b32 (three-input XOR) missing from the hash loop"
+    assert seen >= 8, seen  # 4 instantiations (Hpc / Regular x descriptor / legacy) per translation unit
