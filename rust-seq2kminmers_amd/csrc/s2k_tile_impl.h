@@ -234,9 +234,16 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * (
             S2K_OUT(0) S2K_OUT(1) S2K_OUT(2) S2K_OUT(3) S2K_OUT(4) S2K_OUT(5) S2K_OUT(6) S2K_OUT(7)
 #undef S2K_OUT
         }
-        if constexpr (S < L) { // warm-up: first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174)
-            fh = __builtin_rotateleft32(fh, 1) ^ EI[S].x;
-            rh = __builtin_rotateright32(rh, 1) ^ EI[S].y;
+        if constexpr (S < L) { // warm-up: first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174), in closed form: base i enters
+            // as rotl(h, l-1-i) / rotl(rc-entry, i) -- EI.y holds rotl(rc, l-1), so rotr by l-1-i --, two bases per three-input XOR
+            // (three instructions per strand and pair instead of four for two rolling steps)
+            if constexpr (S % 2 == 1) {
+                fh = xor3(fh, __builtin_rotateleft32(EI[S - 1].x, (L - S) & 31), __builtin_rotateleft32(EI[S].x, (L - 1 - S) & 31));
+                rh = xor3(rh, __builtin_rotateright32(EI[S - 1].y, (L - S) & 31), __builtin_rotateright32(EI[S].y, (L - 1 - S) & 31));
+            } else if constexpr (S == L - 1) { // odd l: the last base alone, rotation 0
+                fh ^= EI[S].x;
+                rh ^= EI[S].y;
+            }
         } else {
             constexpr int P = S - L;
             const uint32_t hv = fh < rh ? fh : rh;                              // canonical (src/nthash_hpc.rs:276)
