@@ -9,7 +9,9 @@ pkg = import_package()
 eng = pkg.Engine(0)
 dev = torch.device("cuda", 0)
 names = {"regular": pkg.HashMode.Regular, "hpc": pkg.HashMode.Hpc, "simd": pkg.HashMode.Simd, "hpcsimd": pkg.HashMode.HpcSimd}
-modes = [names[a] for a in sys.argv[1:]] or list(names.values())
+L = [int(a[2:]) for a in sys.argv[1:] if a.startswith("l=")]
+L = L[0] if L else 31  # l=25: a value without a compile-time instantiation takes the run-time-l hash loop
+modes = [names[a] for a in sys.argv[1:] if a in names] or list(names.values())
 n_reads, rl = 1_000_000, 10_000
 n_bases = n_reads * rl
 off = (np.arange(n_reads + 1, dtype=np.int64) * rl)
@@ -23,10 +25,10 @@ o = pkg.DeviceOut(); o.km_capacity = cap
 o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
 torch.cuda.synchronize()
 for mode in modes:
-    eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, 31, 10, 0.01, int(mode), o)
+    eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, L, 10, 0.01, int(mode), o)
     ts = []
     for _ in range(5):
         t0 = time.perf_counter()
-        c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, 31, 10, 0.01, int(mode), o)
+        c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, L, 10, 0.01, int(mode), o)
         ts.append(time.perf_counter() - t0)
-    print("%-8s chunks=%s  best %.3f ms  median %.3f ms  %.1f Gbp/s  kminmers=%d" % (mode.name, os.environ.get("S2K_DESC_CHUNKS", "default"), min(ts) * 1e3, sorted(ts)[2] * 1e3, n_bases / min(ts) / 1e9, c["n_kminmers"]), flush=True)
+    print("%-8s l=%d chunks=%s  best %.3f ms  median %.3f ms  %.1f Gbp/s  kminmers=%d" % (mode.name, L, os.environ.get("S2K_DESC_CHUNKS", "default"), min(ts) * 1e3, sorted(ts)[2] * 1e3, n_bases / min(ts) / 1e9, c["n_kminmers"]), flush=True)
