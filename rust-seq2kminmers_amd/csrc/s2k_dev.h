@@ -80,7 +80,6 @@ struct Counts { // mirrored by s2k_counts (include/s2k.h)
     uint32_t pool_overflow, bad_input, km_overflow, mn_overflow; // bad_input: BAD_* bits set by validate_read_off_kernel
     uint32_t need_legacy, need_runs; // need_runs: HpcSimd: a look-back for the run heads of earlier tiles gave up (bounded polls): the host re-runs the call with the
                                      // runs of every read counted first.  need_legacy: descriptor path: a tile it cannot handle was met (> 30 read starts, a span >= 2^18): the host re-runs the call through the legacy path
-    // fused path: a tile it cannot handle was met (or a look-back timed out): the host re-runs the call unfused
     uint64_t dbg_cycles[64][16]; // S2K_DEBUG_SKIP & 8: shader-clock cycles per phase, summed over waves
 #ifdef S2K_DEBUG_KNOBS
     uint64_t dbg_wave[4096][2];  // S2K_DEBUG_SKIP & 32: per wave {finish time (100 MHz) , XCC_ID << 32 | HW_ID}

@@ -1480,8 +1480,6 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
             if (!issued) issue_next(n_rec, rec_base);
             issued = true;
         };
-        // fused: the ~30 words of output pointers and capacities are read from memory HERE, once per tile (scalar loads), instead of
-        // being kernel arguments that live in SGPRs across the hash loop (they cost 26 spilled VGPRs there)
         // The dense phase gets its OWN copy of the lane index, opaque to the compiler: everything it derives from the lane (a dozen
         // masks, offsets and 64-bit zero-extensions) is otherwise loop-invariant, gets hoisted out of the tile loop and lives --
         // or is spilled -- across the hash loop, which is where the register pressure peaks.
