@@ -43,6 +43,9 @@ for it in range(iters):
             else: lens.append(int(rng.integers(1000, 30000)))
     hp = float(rng.choice([0.0, 0.2, 0.5, 0.9])); odd = float(rng.choice([0.0, 0.0, 0.03, 0.3]))
     alphabet = b"ACGT" if rng.random() < 0.8 else b"AC"
+    if os.environ.get("FUZZ_LOWC"):  # low-complexity sequence and dense minimizers: tiles overflow their slabs, pools are re-sized
+        hp = float(rng.choice([0.5, 0.9, 0.97])); alphabet = b"AC" if rng.random() < 0.7 else b"A"
+        d = float(rng.choice([0.05, 0.1, 0.5, 1.0]))
     reads = [rand_read(rng, n, hp=hp, alphabet=alphabet, odd=odd) for n in lens]
     if rng.random() < 0.2:
         eng.set_host_batch(int(rng.integers(2000, 200000)))
