@@ -250,7 +250,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(m, steps, warmup):
+    def timed(m, steps, warmup, strict=True):
         for _ in range(warmup):
             step(m)
         eng.sync()
@@ -266,7 +266,11 @@ def main():
         km_ms, _ = eng.timing_total(2)
         all_ms, _ = eng.timing_total(0)
         eng.enable_timing(False)
-        assert k_n == steps, "internal re-runs (workspace growth) inside the timed region: %d event sets for %d steps" % (k_n, steps)
+        # (strict: the headline must not hide a second run of a call inside its time; the compatibility modes only report it --
+        # HpcSimd re-runs a call with a run-count pre-pass when a look-back for run heads gives up, which happens when several
+        # processes share one GPU and no minimizer kernel has all its waves resident, i.e. in --single-device rehearsals)
+        assert k_n == steps or not strict, "internal re-runs (workspace growth) inside the timed region: %d event sets for %d steps" % (k_n, steps)
+        timed.reruns = k_n - steps
         spread = None
         if dist is not None:
             t = torch.tensor([dt, -dt, all_ms / steps, -(all_ms / steps)], dtype=torch.float64, device=red_dev)
@@ -333,10 +337,11 @@ def main():
         compat = {}
         for nm, hm in (("simd", pkg.HashMode.Simd), ("hpcsimd", pkg.HashMode.HpcSimd)):
             s3 = max(2, args.steps // 4)
-            dt3, counts3, _, _, pipe_ms3, _ = timed(hm, s3, 1)
+            dt3, counts3, _, _, pipe_ms3, _ = timed(hm, s3, 1, strict=False)
             assert counts3["path"] == (2 if args.legacy_path else 0)
             tot3 = sharding.allreduce_counts(counts3, dist, red_dev)
-            compat[nm] = {"value": round(tot3["n_bases"] * s3 / dt3 / 1e9, 2), "unit": "Gbp/s", "pipeline_ms": round(pipe_ms3, 3), "kminmers": int(tot3["n_kminmers"])}
+            compat[nm] = {"value": round(tot3["n_bases"] * s3 / dt3 / 1e9, 2), "unit": "Gbp/s", "pipeline_ms": round(pipe_ms3, 3), "kminmers": int(tot3["n_kminmers"]),
+                          "calls_run_again": int(timed.reruns)}
         other_line["compat_modes"] = compat
 
     # whole-job counts: the only collective on this path (RCCL all-reduce of a few words)
