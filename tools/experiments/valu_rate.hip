@@ -113,6 +113,15 @@ KERNEL(bfi, A_BFI, "memory")
 KERNEL(xorsdwa, A_XORSDWA, "memory")
 KERNEL(xorxor, A_PKXOR, "memory")
 
+// round 3: operands from three different registers, and the hash step's own mix (one strand: rotate, three-input XOR, min, compare,
+// select, add-with-carry) -- does an instruction cost more inside the kernel than in the one-instruction loops above?
+#define A_BITOP3(i) "v_bitop3_b32 %" #i ", %" #i ", %8, %9 bitop3:0x96\n\t"
+#define A_ALIGN2(i) "v_alignbit_b32 %" #i ", %" #i ", %8, 31\n\t"
+#define A_HSTEP(i) "v_alignbit_b32 %" #i ", %" #i ", %" #i ", 31\n\tv_bitop3_b32 %" #i ", %" #i ", %8, %9 bitop3:0x96\n\tv_min_u32 v40, %" #i ", %8\n\tv_cmp_ge_u32 vcc, %10, v40\n\tv_cndmask_b32 v41, v41, v40, vcc\n\tv_addc_co_u32 v42, vcc, v42, v42, vcc\n\t"
+KERNEL(bitop3, A_BITOP3, "memory")
+KERNEL(align2, A_ALIGN2, "memory")
+KERNEL(hstep, A_HSTEP, "vcc", "v40", "v41", "v42")
+
 // LDS table look-ups as in the hash loop: ds_read_b64 of one of 4 entries per lane
 __global__ __launch_bounds__(256) void k_ldsb64(uint32_t *out, uint64_t *cyc, int iters, uint32_t s) {
     __shared__ uint2 tab[512];
@@ -169,7 +178,8 @@ int main() {
                     {"v_cmp_e64 ->sgpr", k_cmps, 32}, {"v_cndmask_sdwa", k_cndsdwa, 32}, {"min+xor (2)", k_minxor, 64},
                     {"v_lshlrev_b32", k_lshl, 32}, {"v_and_b32", k_and_, 32}, {"v_sub_u32", k_sub, 32}, {"v_max_u32", k_max, 32},
                     {"v_lshlrev_b64", k_lshl64, 32}, {"v_mad_u32_u24", k_madu24, 32}, {"v_bfi_b32", k_bfi, 32},
-                    {"v_xor_b32_sdwa", k_xorsdwa, 32}, {"xor+xor (2)", k_xorxor, 64}, {"v_sub_co_u32", k_subco, 32}, {"sub_co+cnd+addc (3)", k_track3, 96}};
+                    {"v_xor_b32_sdwa", k_xorsdwa, 32}, {"xor+xor (2)", k_xorxor, 64}, {"v_sub_co_u32", k_subco, 32}, {"sub_co+cnd+addc (3)", k_track3, 96},
+                    {"v_bitop3_b32 (3 regs)", k_bitop3, 32}, {"v_alignbit (2 regs)", k_align2, 32}, {"hash step mix (6)", k_hstep, 192}};
     const int iters = 20000;
     printf("%-22s", "cycles/wave-instr/SIMD");
     for (int wps : {1, 2, 3, 4, 8}) printf("  %dw/SIMD", wps);
