@@ -81,8 +81,14 @@ constexpr int MAX_L_TILED = 64;
 #endif
 constexpr int LISTCAP = S2K_LISTCAP;                           // hits handled per dense batch
 constexpr int JOBCAP = S2K_JOBCAP;                             // queued hash re-derivations per flush
-constexpr int REG_LA = 1;
-constexpr int HPC_LA = 2;                              // seed look-ahead (positions) of the Hpc hash loop: 8 spills there
+#ifndef S2K_REG_LA
+#define S2K_REG_LA 1
+#endif
+#ifndef S2K_HPC_LA
+#define S2K_HPC_LA 2
+#endif
+constexpr int REG_LA = S2K_REG_LA;                     // seed look-ahead (positions) of the hash loop: the LDS round trip of a look-up is covered by
+constexpr int HPC_LA = S2K_HPC_LA;                     // LA positions of the lane's own arithmetic (4 registers per position of look-ahead)
 constexpr int NBL = 32;                                // read starts of a tile kept in LDS (hb / rs16); tiles with more search the read table
 // vector-memory operations one round of 64 hits issues: the counted vmcnt wait relies on it (tools/isa/check_vmcnt.py checks it).
 // Descriptor path: one store ({offset in the tile, span}); legacy path: three (j, jend, read index).
@@ -107,9 +113,16 @@ struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
     int16_t hb[NBL];         // read starts inside the tile, as hash-space positions (ascending; 0 .. TILE_BASES)
     uint16_t rs16[NBL];      // rs16[i] = read_off[r0 + i] - t0 for the read starts inside the tile (i >= 1; read r0 starts at rs0, kept in a register)
 };
+#ifdef S2K_PROFILE // phase accumulators of the PROFILE build (see S2K_STAMP): 16 x 8 B per wave behind the waves' buffers
+typedef __attribute__((address_space(3))) unsigned long long *ph_ptr_t;
+constexpr int PROFILE_LDS_BYTES = TW * 16 * 8;
+#else
+typedef uint64_t *ph_ptr_t;
+constexpr int PROFILE_LDS_BYTES = 0;
+#endif
 constexpr int TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c], l-1)};  OUT table at 2048: {rotl(h[c], l), rotr(rc[c], 1)}
 template <bool HPC>
-constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>); }
+constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>) + PROFILE_LDS_BYTES; }
 // one block of TW = 12 waves per CU: it may use the whole 160 KiB (MI355X_MICROARCH.md: "a single workgroup may declare all 160 KiB")
 #ifndef S2K_EXPERIMENT
 static_assert(block_lds_bytes<true>() <= 160 * 1024, "the block of a CU must fit its 160 KiB of LDS");
@@ -167,6 +180,9 @@ __device__ __forceinline__ uint32_t byte_x8(uint32_t w) {
 }
 template <int TABLE_OFF>
 __device__ __forceinline__ uint2 seed_pair(uint32_t off) { // ds_read_b64 v, off offset:TABLE_OFF
+#ifdef HX_NOLDS // (tools/experiments/hash_loop_bench.hip only: the loop without its table look-ups)
+    return make_uint2(off, off);
+#endif
     typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
     const unsigned long long v = *reinterpret_cast<lds_cu64 *>(off + TABLE_OFF);
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
@@ -187,6 +203,10 @@ __device__ __forceinline__ uint2 tab_out(const uint2 *tab, uint32_t c) { return 
 // One position of the hot loop.  The hit test, the capture of the hit's hash and the hit bit are three
 // VALU instructions chained through VCC (compare -> select -> add-with-carry shifts the bit in).
 __device__ __forceinline__ void hit_track(uint32_t hv, uint32_t bound, uint32_t &cap, uint32_t &bits) {
+#ifdef HX_NOTRACK // (tools/experiments/hash_loop_bench.hip only: the loop without compare / select / add-with-carry)
+    bits ^= hv;
+    return;
+#endif
     asm("v_cmp_ge_u32_e32 vcc, %2, %3\n\t"
         "v_cndmask_b32_e32 %0, %0, %3, vcc\n\t"
         "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
@@ -346,24 +366,24 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
 // each and the kernel took 13.2 ms; 64 addresses, 128 B apart, are not a bottleneck.)
 // (s_setprio per phase -- dense phase high and hash loop low, and the reverse -- moved the kernel by <= 1 % either way: not used.)
 
-// Phase stamps (cycles per phase, kept in registers and flushed once per tile to one of 64 shards) exist only in
-// builds with -DS2K_PROFILE (tools/phases.sh): the 16 accumulators cost 32 VGPRs that production kernels need.
+// Phase stamps (cycles per phase, flushed once per wave to one of 64 shards) exist only in builds with -DS2K_PROFILE
+// (tools/phases.sh).  The 16 accumulators of a wave live in LDS (128 B per wave behind the waves' buffers; lane 0 adds to them):
+// in registers (rounds 2-3) they cost 32 VGPRs, i.e. the third wave per SIMD -- and what a phase costs at two waves per SIMD is
+// not what it costs at three.  A stamp is ~8 instructions and drains lgkmcnt; 16 of them per tile perturb the kernel by ~3 %.
+#ifndef S2K_WAVES_PER_SIMD
+#define S2K_WAVES_PER_SIMD 3
+#endif
 #ifdef S2K_PROFILE
-#define S2K_WAVES_PER_SIMD 2 /* the 16 phase accumulators cost 32 VGPRs */
 #define S2K_STAMP(i)                                                                     \
     do {                                                                                 \
         if (sem.dbg_skip & 8) {                                                          \
             uint64_t _n = __builtin_amdgcn_s_memtime();                                  \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
-            ph[i] += _n - stamp;                                                         \
+            if (lane == 0) ph[i] += _n - stamp;                                          \
             stamp = _n;                                                                  \
         }                                                                                \
     } while (0)
 #else
-#ifndef S2K_WAVES_PER_SIMD
-#define S2K_WAVES_PER_SIMD 3
-#endif
-
 #define S2K_STAMP(i) do { (void)ph; (void)stamp; } while (0)
 #endif
 
@@ -381,7 +401,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
                                                 const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
                                                 uint64_t t0, uint32_t tile_len, uint32_t r0, uint32_t r1, uint32_t l,
                                                 int lane, uint32_t &halo_n_out, uint64_t bpos0,
-                                                uint32_t prev_byte0, bool forced0, const Sem &sem, uint64_t *ph,
+                                                uint32_t prev_byte0, bool forced0, const Sem &sem, ph_ptr_t ph,
                                                 uint64_t &stamp) {
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     // 1. read starts strictly inside the tile -> forced run heads, OR-ed into S.fm (cleared by the caller before the
@@ -696,7 +716,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                                                 uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem,
                                                 unsigned long long *__restrict__ d_agg, TileMeta *__restrict__ d_meta, uint32_t K1,
                                                 const uint32_t (&caps)[NPC], const uint32_t (&raw)[5], uint32_t lb_early,
-                                                bool &lb_dead, uint64_t *ph, uint64_t &stamp) {
+                                                bool &lb_dead, ph_ptr_t ph, uint64_t &stamp) {
     // (1) read starts that matter for this tile -> hash-space boundaries HB; an l-mer x is invalid iff
     //     some boundary has HB - w <= x <= HB - 1  (w = l-1 raw positions for Regular: the l-mer must end
     //     before the next read, src/lib.rs:215-230; w = l run heads for Hpc: head x+l must exist in the
@@ -1071,7 +1091,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             const bool need = (e & 0x8000u) != 0;
             uint64_t jobs = __ballot(need);
 #ifdef S2K_PROFILE
-            if (sem.dbg_skip & 8) ph[7] += (uint64_t)__popcll(jobs);
+            if ((sem.dbg_skip & 8) && lane == 0) ph[7] += (uint64_t)__popcll(jobs);
 #endif
             if (sem.dbg_skip & 64) jobs = 0;
             while (jobs) { // wave-uniform: queue up to JOBCAP jobs, flush, queue the rest
@@ -1222,7 +1242,13 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     if (t >= n_tiles) return;
     if (__builtin_amdgcn_readfirstlane((int)counts->bad_input)) return; // malformed read table (validate_read_off_kernel): touch nothing
     uint64_t stamp = __builtin_amdgcn_s_memtime();
-    uint64_t ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef S2K_PROFILE
+    ph_ptr_t ph = reinterpret_cast<ph_ptr_t>((uint32_t)(TABLE_BYTES + TW * sizeof(WL) + (size_t)w * 128)); // (the dynamic region starts at LDS address 0)
+    if (lane0 < 16) ph[lane0] = 0;
+    wave_sync();
+#else
+    ph_ptr_t ph = nullptr;
+#endif
 
     // a tile is "full" when the tile and its 128 B look-ahead lie inside the stream: staged branch-free
     auto is_full = [&](uint64_t tt) { return (tt + 1) * (uint64_t)TILE_BASES + 128 <= n_bases; };
