@@ -8,6 +8,9 @@ Workloads (BASELINE.json configs):
       [1 k, 200 k], 1.25 M reads (~25 Gbp) per GPU, i.e. 10 M reads / ~200 Gbp on 8 GPUs -- cut into contiguous
       shards balanced by cumulative bases (sharding.shard_bounds); rank r runs the HIP path on its shard.
       value = all bases / slowest shard's time, so the load balance over ragged lengths is part of the number.
+  hifi (configs[3])          per GPU 1 000 000 HiFi-like reads (~15 Gbp): lengths ~N(15 k, 2 k), homopolymer runs of geometric length
+      with mean 2, ~0.1 % of them 20..2999 bases long, generated in HBM by s2k_synth_hifi_device; the default
+      c2 run also reports its rate (and that of configs[4], 1 Mbp contigs at d = 0.001) under "other_configs".
 Bases are generated in HBM by the library's splitmix64 generator (rank r generates exactly its part of the one
 global stream).  A "step" is one pass of the whole hot path (s2k_extract_device: tile index + minimizer kernel + scans +
 k-min-mer kernel) over the resident batch.  Reads shard across GPUs with no data-path collective; the only cross-GPU
@@ -41,7 +44,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["c2", "ont"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "ont", "hifi"], default="c2")
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default 1 000 000 for c2, 1 250 000 for ont)")
     ap.add_argument("--read-len", type=int, default=10_000, help="c2: read length")
     ap.add_argument("--l", type=int, default=31)
@@ -65,6 +68,8 @@ def parse_args():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive legs (host->host s2k_extract, s2k_run_file) that N=1 runs after the timed region")
     ap.add_argument("--e2e-reads", type=int, default=400_000, help="reads (of --read-len bases) of the PCIe-inclusive legs: 4 Gbp by default")
     ap.add_argument("--legacy-path", action="store_true", help="legacy records (16 B with the read index + per-read scans) instead of the descriptor path")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the rates of BASELINE configs[3] / configs[4] and of the 'next' rows "
+                                                                    "(standalone HPC, minimizer triples) that the default c2 run reports beside the headline (--no-other-mode skips them too)")
     ap.add_argument("--dump-shard", default=None, help="(tests) write this rank's outputs to <path>.rank<r>.npz")
     return ap.parse_args()
 
@@ -123,6 +128,19 @@ def usable_cpus():
         except (OSError, ValueError):
             continue
     return n
+
+
+def kernel_source_id():
+    """sha256 over the device sources of the library (csrc/*.hip, *.h, Makefile): what a committed PMC measurement belongs to"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rust-seq2kminmers_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def ont_lengths(n_reads, seed=2):
@@ -208,6 +226,16 @@ def main():
         host_off = None
         shard_info = {"reads_per_gpu": n_reads, "read_len": rl, "sharding": "reads, contiguous per rank"}
         wl_text = "%d x %d bp uniform-random ACGT reads per GPU (%.1f Gbp/GPU)" % (n_reads, rl, n_bases / 1e9)
+    elif args.workload == "hifi":
+        n_reads, seed = args.reads or 1_000_000, 3
+        r_first = rank * n_reads  # each rank owns its own reads of the one numbered sequence of reads
+        hl = eng.synth_hifi_lengths(seed, r_first, n_reads)
+        host_off = np.concatenate(([0], np.cumsum(hl))).astype(np.uint64)
+        n_bases, first_base = int(host_off[-1]), 0
+        d_off = torch.from_numpy(host_off.astype(np.int64)).to(dev)
+        shard_info = {"reads_per_gpu": n_reads, "sharding": "reads, contiguous per rank"}
+        wl_text = "%d HiFi-like reads per GPU, lengths ~N(15k, 2k), geometric homopolymer runs of mean 2, ~0.1%% of the runs 20..2999 bases (%.1f Gbp/GPU)" % (
+            n_reads, n_bases / 1e9)
     else:
         per_gpu = args.reads or 1_250_000
         total_reads = args.total_reads if args.scaling == "strong" else per_gpu * world
@@ -231,7 +259,10 @@ def main():
         wl_text = "%d ragged reads, lognormal(mean 20 kbp, sigma 0.5) clipped [1k,200k] (%.1f Gbp) in %d shard(s), %s scaling" % (
             len(lens), int(goff[-1]) / 1e9, world, args.scaling)
     d_bases = torch.empty(n_bases + 256, dtype=torch.uint8, device=dev)
-    eng.synth_bases_device(seed, first_base, n_bases, d_bases.data_ptr())
+    if args.workload == "hifi":
+        eng.synth_hifi_device(seed, r_first, n_reads, d_off.data_ptr(), d_bases.data_ptr())
+    else:
+        eng.synth_bases_device(seed, first_base, n_bases, d_bases.data_ptr())
     cap = int(n_bases * (2.4 * args.density)) + 1_000_000
     outs = {"km_off": torch.empty(n_reads + 1, dtype=torch.int64, device=dev), "hash": torch.empty(cap, dtype=torch.int64, device=dev),
             "start": torch.empty(cap, dtype=torch.int32, device=dev), "end": torch.empty(cap, dtype=torch.int32, device=dev),
@@ -300,7 +331,8 @@ def main():
         voff = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
         hb = np.empty(int(voff[-1]), dtype=np.uint8)
         for i in range(len(ids)):
-            hb[int(voff[i]): int(voff[i + 1])] = orc.synth_bases(seed, first_base + int(starts[i]), int(lens[i]))
+            hb[int(voff[i]): int(voff[i + 1])] = (orc.hifi_read(seed, r_first + int(ids[i]), int(lens[i])) if args.workload == "hifi"
+                                                  else orc.synth_bases(seed, first_base + int(starts[i]), int(lens[i])))
         a0, n0 = int(starts[0]), int(min(lens[0], 4096))
         assert (d_bases[a0: a0 + n0].cpu().numpy() == hb[:n0]).all(), "device generator and oracle generator disagree"
         ref = orc.batch(hb, voff, args.l, args.k, args.density, so.HPC if mode == pkg.HashMode.Hpc else so.REGULAR, threads=4)
@@ -343,6 +375,109 @@ def main():
             compat[nm] = {"value": round(tot3["n_bases"] * s3 / dt3 / 1e9, 2), "unit": "Gbp/s", "pipeline_ms": round(pipe_ms3, 3), "kminmers": int(tot3["n_kminmers"]),
                           "calls_run_again": int(timed.reruns)}
         other_line["compat_modes"] = compat
+
+    # ---- rates the headline does not show, N = 1, outside the timed region: the other BASELINE configs that fit one GPU and the
+    #      "next" rows of SURVEY.md 8f (standalone HPC = src/hpc.rs, README.md:23 "HPC alone"; minimizer triples = the iterators of
+    #      src/nthash_hpc.rs:193) -----------------------------------------------------------------------------------------------
+    other_configs = standalone_hpc = minimizers_only = None
+    if rank == 0 and world == 1 and args.workload == "c2" and not args.no_other_configs and not args.no_other_mode and not args.legacy_path:
+        def rate(d_b, d_o, nr, nb, m, dens, out, steps=3, flags=0):
+            def one():
+                return eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), nr, nb, args.l, args.k, dens, m, out, sync=False, flags=flags)
+            one()
+            eng.sync()
+            eng.enable_timing(True)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            c = eng.sync()
+            torch.cuda.synchronize(dev)
+            dtx = time.perf_counter() - t0
+            all_ms, n_ev = eng.timing_total(0)
+            k_ms, _ = eng.timing_total(1)
+            eng.enable_timing(False)
+            return {"value": round(nb * steps / dtx / 1e9, 2), "unit": "Gbp/s", "ms_per_step": round(dtx / steps * 1e3, 3), "pipeline_ms": round(all_ms / steps, 3),
+                    "kernel_ms": round(k_ms / steps, 3), "bases": int(nb), "reads": int(nr), "minimizers": c["n_minimizers"], "kminmers": c["n_kminmers"],
+                    "roofline_frac": round((nb + 17 * c["n_kminmers"] + 16 * (nr + 1)) / (all_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "calls_run_again": int(n_ev - steps)}
+
+        def out_for(nr, cap):
+            t = {"km_off": torch.empty(nr + 1, dtype=torch.int64, device=dev), "hash": torch.empty(cap, dtype=torch.int64, device=dev),
+                 "start": torch.empty(cap, dtype=torch.int32, device=dev), "end": torch.empty(cap, dtype=torch.int32, device=dev),
+                 "rev": torch.empty(cap, dtype=torch.uint8, device=dev)}
+            oo = pkg.DeviceOut()
+            oo.km_capacity = cap
+            oo.km_off, oo.hash, oo.start, oo.end, oo.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+            return t, oo
+
+        other_configs = {}
+        # BASELINE configs[3]: HiFi-like reads, HPC on (the one input on which the Hpc kernel's data-dependent parts matter:
+        # run heads beyond the staged look-ahead, long spans in the back-map, src/nthash_hpc.rs:253-263,280-281)
+        nr3 = 1_000_000
+        hl = eng.synth_hifi_lengths(3, 0, nr3)
+        hoff3 = np.concatenate(([0], np.cumsum(hl))).astype(np.int64)
+        nb3 = int(hoff3[-1])
+        d_o3 = torch.from_numpy(hoff3).to(dev)
+        d_b3 = torch.empty(nb3 + 256, dtype=torch.uint8, device=dev)
+        eng.synth_hifi_device(3, 0, nr3, d_o3.data_ptr(), d_b3.data_ptr())
+        t3, o3 = out_for(nr3, int(nb3 * 0.0135) + 1_000_000)
+        c3 = {"name": "BASELINE configs[3]", "workload": "%d HiFi-like reads (%.1f Gbp): lengths ~N(15k, 2k), geometric homopolymer runs of mean 2, ~0.1%% of the runs 20..2999 bases; d=%g" % (
+            nr3, nb3 / 1e9, args.density)}
+        for nm, hm in (("hpc", pkg.HashMode.Hpc), ("hpcsimd", pkg.HashMode.HpcSimd), ("regular", pkg.HashMode.Regular)):
+            c3[nm] = rate(d_b3, d_o3, nr3, nb3, hm, args.density, o3)
+        other_configs["hifi"] = c3
+        del d_b3, d_o3, t3, o3
+        # BASELINE configs[4]: 1 Mbp contigs at d = 0.001 (sparse minimizers)
+        nr4, rl4 = 10_000, 1_000_000
+        d_o4 = torch.arange(0, nr4 + 1, dtype=torch.int64, device=dev) * rl4
+        d_b4 = torch.empty(nr4 * rl4 + 256, dtype=torch.uint8, device=dev)
+        eng.synth_bases_device(4, 0, nr4 * rl4, d_b4.data_ptr())
+        t4, o4 = out_for(nr4, int(nr4 * rl4 * 0.0026) + 1_000_000)
+        c4 = {"name": "BASELINE configs[4]", "workload": "%d x %d bp uniform-random contigs (%.1f Gbp), d=0.001" % (nr4, rl4, nr4 * rl4 / 1e9)}
+        for nm, hm in (("hpc", pkg.HashMode.Hpc), ("regular", pkg.HashMode.Regular)):
+            c4[nm] = rate(d_b4, d_o4, nr4, nr4 * rl4, hm, 0.001, o4)
+        other_configs["contigs"] = c4
+        del d_b4, d_o4, t4, o4
+        torch.cuda.empty_cache()
+
+        # minimizer triples (start, end, hash32) beside the k-min-mers: S2K_FLAG_WANT_MINIMIZERS on the headline workload
+        mcap = int(n_bases * 2.2 * args.density) + 1_000_000
+        tm = {"mn_off": torch.empty(n_reads + 1, dtype=torch.int64, device=dev), "mn_j": torch.empty(mcap, dtype=torch.int32, device=dev),
+              "mn_jend": torch.empty(mcap, dtype=torch.int32, device=dev), "mn_hash": torch.empty(mcap, dtype=torch.int32, device=dev)}
+        o.mn_capacity = mcap
+        o.mn_off, o.mn_j, o.mn_jend, o.mn_hash = (tm[x].data_ptr() for x in ("mn_off", "mn_j", "mn_jend", "mn_hash"))
+        minimizers_only = {"what": "s2k_extract_device with S2K_FLAG_WANT_MINIMIZERS on the headline workload: k-min-mers AND the minimizer triples "
+                                   "(start, end, hash32) of the iterators of src/nthash_hpc.rs:193 / src/nthash_avx512_32.rs:14 (+12 B per minimizer written)"}
+        for nm, hm in ((args.mode, mode), ("regular" if args.mode == "hpc" else "hpc", other)):
+            minimizers_only[nm] = rate(d_bases, d_off, n_reads, n_bases, hm, args.density, o, flags=pkg.FLAG_WANT_MINIMIZERS)
+        o.mn_capacity = 0
+        o.mn_off = o.mn_j = o.mn_jend = o.mn_hash = None
+        del tm
+
+        # standalone homopolymer compression (src/hpc.rs:7-147: compressed bytes + run starts): 2 Gbp of the headline workload
+        nrh = min(n_reads, 200_000)
+        nbh = int(host_off[nrh]) if host_off is not None else nrh * args.read_len
+        hcap = int(nbh * 0.80) + 4096
+        th = {"off": torch.empty(nrh + 1, dtype=torch.int64, device=dev), "hpc": torch.empty(hcap, dtype=torch.uint8, device=dev),
+              "pos": torch.empty(hcap, dtype=torch.int32, device=dev)}
+        standalone_hpc = {"what": "s2k_hpc_device(_ex) on the first %d reads (%.1f Gbp): compressed string + read-relative run starts per read, resident in HBM; "
+                                  "best of 3 wall-clock calls; the reference's comparator is README.md:23 'HPC alone ~4 GB/s' (AVX-512, one thread)" % (nrh, nbh / 1e9),
+                          "unit": "Gbp/s"}
+        for nm, rle in (("hpc / encode_rle_simd (any repeated byte collapses, src/hpc.rs:28-41,44-147)", False),
+                        ("encode_rle (only ACTGactgNn collapse, src/hpc.rs:7-25)", True)):
+            best, runs = None, 0
+            for _ in range(4):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                runs = eng.hpc_device(d_bases.data_ptr(), d_off.data_ptr(), nrh, nbh, th["off"].data_ptr(), th["hpc"].data_ptr(), th["pos"].data_ptr(), hcap, rle=rle)
+                torch.cuda.synchronize(dev)
+                dth = time.perf_counter() - t0
+                best = dth if best is None else min(best, dth)
+            standalone_hpc[nm] = {"value": round(nbh / best / 1e9, 1), "ms": round(best * 1e3, 3), "runs": int(runs),
+                                  "algorithmic_gb_s": round((nbh + 5 * runs + 8 * (nrh + 1)) / best / 1e9, 1)}
+        del th
+        torch.cuda.empty_cache()
 
     # whole-job counts: the only collective on this path (RCCL all-reduce of a few words)
     tot = sharding.allreduce_counts(counts, dist, red_dev)
@@ -389,17 +524,22 @@ def main():
     achieved = alg_bytes / (pipe_ms * 1e-3) / 1e9
     # the dominant kernel on its own: it reads the bases and the read table once and writes 8 B per minimizer record (16 B on the legacy path)
     kern_bytes = counts["n_bases"] + (16 if args.legacy_path else 8) * counts["n_minimizers"] + 8 * (n_reads + 1)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_stale = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath) and args.workload == "c2":
         try:
             tj = json.load(open(tpath))
             if tj.get("mode") == args.mode and tj.get("n_bases") == n_bases:
-                traffic, traffic_src = tj.get("hbm_bytes_per_step"), tj.get("source")
+                # the PMC passes belong to ONE state of the kernels: the file carries the id of the sources it was measured on
+                if tj.get("kernel_source_id") == kernel_source_id():
+                    traffic, traffic_src = tj.get("hbm_bytes_per_step"), tj.get("source")
+                else:
+                    traffic_stale = {"measured_on": tj.get("kernel_source_id"), "sources_now": kernel_source_id(), "stale_value": tj.get("hbm_bytes_per_step"),
+                                     "how_to_refresh": "tools/profile.sh on the GPU box, then commit profiles/traffic_latest.json"}
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                 "algorithmic_bytes_per_step": int(alg_bytes), "bytes_per_base": round(alg_bytes / max(n_bases, 1), 4),
                 "time_ms": round(pipe_ms, 3), "time": "HIP events around all kernels of a step (s2k_timing_total(0)), averaged over the timed steps",
                 "kernel": "tile_minimizer_kernel<%d,%s>" % (args.l, "hpc" if mode == pkg.HashMode.Hpc else "regular"),
@@ -517,11 +657,12 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": dict({"workload": "%s, HashMode::%s, l=%d k=%d d=%g; inputs resident in HBM" % (
                 wl_text, "Hpc" if mode == pkg.HashMode.Hpc else "Regular", args.l, args.k, args.density),
-                "name": "BASELINE configs[1]" if args.workload == "c2" else "BASELINE configs[2]", "mode": args.mode,
+                "name": {"c2": "BASELINE configs[1]", "ont": "BASELINE configs[2]", "hifi": "BASELINE configs[3]"}[args.workload], "mode": args.mode,
                 "largest_shard_over_mean": balance}, **shard_info),
             "counts": {"bases": tot_bases, "minimizers": tot_min, "kminmers": tot_km, "xor_hash_rank0": counts["xor_hash"]},
             "verified_vs_oracle": verified,
-            "other_mode": other_line, "downstream_count": count_line, "collective": collective, "per_rank": rank_spread,
+            "other_mode": other_line, "other_configs": other_configs, "standalone_hpc": standalone_hpc, "minimizers_only": minimizers_only,
+            "downstream_count": count_line, "collective": collective, "per_rank": rank_spread,
             "end_to_end": e2e,
             "roofline": roofline, "cpu_baseline": cpu,
         }

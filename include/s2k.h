@@ -210,6 +210,13 @@ s2k_status s2k_partition_device(s2k_ctx *ctx, const uint64_t *d_hash, uint64_t n
 /* Fills d_bases[0..n) with the deterministic synthetic ACGT stream (splitmix64 keyed by seed and
  * absolute base index; same function as oracle/s2k_oracle.c:s2k_oracle_synth_bases). */
 s2k_status s2k_synth_bases_device(s2k_ctx *ctx, uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_bases);
+/* HiFi-like synthetic reads (BASELINE configs[3]: lengths ~N(15 000, 2 000), homopolymer runs of geometric length with mean 2,
+ * ~0.1 % of them stretched to 20..2999 bases; splitmix64 keyed by (seed, read index); same functions as the oracle's
+ * s2k_oracle_hifi_len / s2k_oracle_hifi_read).  s2k_synth_hifi_lengths fills a HOST array with the lengths of reads
+ * r0 .. r0+n_reads-1; s2k_synth_hifi_device writes read r0+i at d_bases + d_read_off[i] (d_read_off: device, n_reads+1 entries,
+ * the prefix sums of those lengths). */
+void s2k_synth_hifi_lengths(uint64_t seed, uint64_t r0, uint64_t n_reads, uint64_t *lengths);
+s2k_status s2k_synth_hifi_device(s2k_ctx *ctx, uint64_t seed, uint64_t r0, uint64_t n_reads, const uint64_t *d_read_off, uint8_t *d_bases);
 /* Duration in ms of the kernels of the last s2k_extract_device call, measured with HIP events on the
  * context's stream: which: 0 = whole pipeline (first kernel's start to the last one's end), 1 = the minimizer kernel (dominant; the
  * descriptor path launches it once per chunk of tiles: first start to last end), 2 = scan + k-min-mer kernels (first start to last

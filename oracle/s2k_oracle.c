@@ -819,6 +819,41 @@ uint64_t s2k_oracle_batch_count_timed(const uint8_t *bases, const uint64_t *off,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * HiFi-like synthetic reads (SURVEY.md 8d C4 / BASELINE configs[3]): read r is a sequence of homopolymer runs drawn from
+ * splitmix64 keyed by (seed, r) -- run lengths geometric with mean 2, about 0.1 % of the runs stretched to 20..2999 bases (so
+ * that the l+1 run heads an l-mer needs overflow any fixed look-ahead), consecutive runs of different letters -- and its length
+ * is ~N(15 000, 2 000) (eight 16-bit uniforms, integer arithmetic only), clipped to [2 000, 30 000].  The device generator of
+ * the product library (csrc/s2k_util.hip: synth_hifi_kernel) implements the identical functions.
+ * ---------------------------------------------------------------------------------------- */
+static inline uint64_t splitmix64(uint64_t z);
+static inline uint64_t hifi_key(uint64_t seed, uint64_t r) { return seed ^ (r * 0xA24BAED4963EE407ULL) ^ 0x9FB21C651E98DF25ULL; }
+
+uint64_t s2k_oracle_hifi_len(uint64_t seed, uint64_t r) {
+    const uint64_t z0 = splitmix64(hifi_key(seed, r) ^ 0x5851F42D4C957F2DULL), z1 = splitmix64(z0);
+    int64_t s = 0;
+    for (int i = 0; i < 4; i++) s += (int64_t)((z0 >> (16 * i)) & 0xFFFF) + (int64_t)((z1 >> (16 * i)) & 0xFFFF);
+    int64_t len = 15000 + ((s - 262140) * 2000) / 53510; /* eight uniforms: mean 262 140, sigma 53 510 */
+    return (uint64_t)(len < 2000 ? 2000 : len > 30000 ? 30000 : len);
+}
+
+void s2k_oracle_hifi_lens(uint64_t seed, uint64_t r0, uint64_t n, uint64_t *out) {
+    for (uint64_t i = 0; i < n; i++) out[i] = s2k_oracle_hifi_len(seed, r0 + i);
+}
+
+void s2k_oracle_hifi_read(uint64_t seed, uint64_t r, uint64_t n, uint8_t *out) {
+    static const char ACGT[4] = {'A', 'C', 'G', 'T'};
+    uint64_t x = splitmix64(hifi_key(seed, r));
+    uint32_t letter = 0;
+    for (uint64_t pos = 0, run = 0; pos < n; run++) {
+        x = splitmix64(x);
+        uint64_t len = 1 + (uint64_t)__builtin_ctz((uint32_t)x | 0x80000000u); /* geometric, mean 2 */
+        if (((x >> 32) & 1023) == 0) len = 20 + ((x >> 42) & 0x3FFF) % 2980;   /* ~0.1 % of the runs */
+        letter = run == 0 ? (uint32_t)(x >> 60) & 3u : (letter + 1u + (uint32_t)((x >> 56) & 15u) % 3u) & 3u;
+        for (; len && pos < n; len--) out[pos++] = (uint8_t)ACGT[letter];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Whole-run checksums of a synthetic batch (n_reads reads of read_len bases cut from the synth_bases stream
  * of `seed`), generated read by read so that BASELINE-size runs (10 Gbp) need no 10 GB host buffer.
  * out = { n_minimizers, n_kminmers, XOR hash, SUM start, SUM end, #rev,
@@ -832,6 +867,7 @@ uint64_t s2k_oracle_batch_count_timed(const uint8_t *bases, const uint64_t *off,
 struct sum_job {
     const uint64_t *off; /* NULL: reads of read_len bases each; else read r = stream [off[r], off[r+1]) */
     uint64_t seed, r0, r1, read_len;
+    int hifi; /* reads generated per read (s2k_oracle_hifi_read) instead of cut from the uniform stream */
     unsigned l, k;
     uint32_t bound;
     int mode;
@@ -853,7 +889,8 @@ static void *sum_worker(void *p) {
     uint64_t *scratch = NULL;
     for (uint64_t r = jb->r0; r < jb->r1; r++) {
         const uint64_t a = jb->off ? jb->off[r] : r * jb->read_len, n = jb->off ? jb->off[r + 1] - a : jb->read_len;
-        s2k_oracle_synth_bases(jb->seed, a, n, buf);
+        if (jb->hifi) s2k_oracle_hifi_read(jb->seed, r, n, buf);
+        else s2k_oracle_synth_bases(jb->seed, a, n, buf);
         size_t M = s2k_oracle_minimizers(buf, n, jb->l, jb->bound, jb->mode, NULL, NULL, NULL, 0);
         size_t c = kminmers_one(buf, n, jb->l, jb->k, jb->bound, jb->mode, h, st, en, rv, ocap, &scratch, &scap);
         /* km_off of this read, counted from the thread's first read */
@@ -879,20 +916,26 @@ static void *sum_worker(void *p) {
 }
 
 static void synth_checksums_impl(uint64_t seed, const uint64_t *off, uint64_t n_reads, uint64_t read_len, unsigned l,
-                                 unsigned k, double density, int mode, int threads, uint64_t out[S2K_NSUM]);
+                                 unsigned k, double density, int mode, int threads, uint64_t out[S2K_NSUM], int hifi);
 
 void s2k_oracle_synth_checksums(uint64_t seed, uint64_t n_reads, uint64_t read_len, unsigned l, unsigned k,
                                 double density, int mode, int threads, uint64_t out[S2K_NSUM]) {
-    synth_checksums_impl(seed, NULL, n_reads, read_len, l, k, density, mode, threads, out);
+    synth_checksums_impl(seed, NULL, n_reads, read_len, l, k, density, mode, threads, out, 0);
 }
 
 void s2k_oracle_synth_checksums_off(uint64_t seed, const uint64_t *off, uint64_t n_reads, unsigned l, unsigned k,
                                     double density, int mode, int threads, uint64_t out[S2K_NSUM]) {
-    synth_checksums_impl(seed, off, n_reads, 0, l, k, density, mode, threads, out);
+    synth_checksums_impl(seed, off, n_reads, 0, l, k, density, mode, threads, out, 0);
+}
+
+/* HiFi-like reads: read r = s2k_oracle_hifi_read(seed, r, off[r+1] - off[r]) (off = prefix of s2k_oracle_hifi_len) */
+void s2k_oracle_hifi_checksums(uint64_t seed, const uint64_t *off, uint64_t n_reads, unsigned l, unsigned k,
+                               double density, int mode, int threads, uint64_t out[S2K_NSUM]) {
+    synth_checksums_impl(seed, off, n_reads, 0, l, k, density, mode, threads, out, 1);
 }
 
 static void synth_checksums_impl(uint64_t seed, const uint64_t *off, uint64_t n_reads, uint64_t read_len, unsigned l,
-                                 unsigned k, double density, int mode, int threads, uint64_t out[S2K_NSUM]) {
+                                 unsigned k, double density, int mode, int threads, uint64_t out[S2K_NSUM], int hifi) {
     tables();
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > n_reads) threads = n_reads ? (int)n_reads : 1;
@@ -904,6 +947,7 @@ static void synth_checksums_impl(uint64_t seed, const uint64_t *off, uint64_t n_
         jobs[t].r0 = n_reads * (uint64_t)t / threads;
         jobs[t].r1 = n_reads * (uint64_t)(t + 1) / threads;
         jobs[t].read_len = read_len;
+        jobs[t].hifi = hifi;
         jobs[t].l = l;
         jobs[t].k = k;
         jobs[t].bound = s2k_oracle_hash_bound(density);

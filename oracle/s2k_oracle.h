@@ -110,6 +110,16 @@ void s2k_oracle_synth_checksums(uint64_t seed, uint64_t n_reads, uint64_t read_l
 void s2k_oracle_synth_checksums_off(uint64_t seed, const uint64_t *off, uint64_t n_reads, unsigned l, unsigned k,
                                     double density, int mode, int threads, uint64_t out[12]);
 
+/* HiFi-like synthetic reads (BASELINE configs[3]): homopolymer runs drawn from splitmix64 keyed by
+ * (seed, read index) -- geometric run lengths of mean 2, ~0.1 % of the runs stretched to 20..2999 bases -- lengths
+ * ~N(15 000, 2 000) clipped to [2 000, 30 000]; identical to the device generator s2k_synth_hifi_device. */
+uint64_t s2k_oracle_hifi_len(uint64_t seed, uint64_t r);
+void s2k_oracle_hifi_lens(uint64_t seed, uint64_t r0, uint64_t n, uint64_t *out);
+void s2k_oracle_hifi_read(uint64_t seed, uint64_t r, uint64_t n, uint8_t *out);
+/* Whole-run checksums (as s2k_oracle_synth_checksums_off) of the reads r = 0 .. n_reads-1, read r of off[r+1] - off[r] bases. */
+void s2k_oracle_hifi_checksums(uint64_t seed, const uint64_t *off, uint64_t n_reads, unsigned l, unsigned k,
+                               double density, int mode, int threads, uint64_t out[12]);
+
 #ifdef __cplusplus
 }
 #endif

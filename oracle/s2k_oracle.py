@@ -95,6 +95,15 @@ class Oracle:
         L.s2k_oracle_synth_checksums.restype = None
         L.s2k_oracle_synth_checksums.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_uint, C.c_double,
                                                  C.c_int, C.c_int, _u64p]
+        L.s2k_oracle_hifi_len.restype = C.c_uint64
+        L.s2k_oracle_hifi_len.argtypes = [C.c_uint64, C.c_uint64]
+        L.s2k_oracle_hifi_lens.restype = None
+        L.s2k_oracle_hifi_lens.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u64p]
+        L.s2k_oracle_hifi_read.restype = None
+        L.s2k_oracle_hifi_read.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u8p]
+        L.s2k_oracle_hifi_checksums.restype = None
+        L.s2k_oracle_hifi_checksums.argtypes = [C.c_uint64, _u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_double,
+                                                C.c_int, C.c_int, _u64p]
         L.s2k_oracle_synth_checksums_off.restype = None
         L.s2k_oracle_synth_checksums_off.argtypes = [C.c_uint64, _u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_double,
                                                      C.c_int, C.c_int, _u64p]
@@ -243,6 +252,24 @@ class Oracle:
         self.lib.s2k_oracle_batch_minimizers(_ptr(bases, _u8p), _ptr(off, _u64p), n_reads, l, density, mode,
                                              _ptr(mn_off, _u64p), _ptr(j, _u32p), _ptr(je, _u32p), _ptr(h, _u32p), tot)
         return {"n": tot, "mn_off": mn_off, "j": j, "jend": je, "hash": h}
+
+    def hifi_lengths(self, seed, r0, n):
+        """lengths of the HiFi-like reads r0 .. r0+n-1 (s2k_oracle_hifi_len)"""
+        out = np.empty(n, dtype=np.uint64)
+        self.lib.s2k_oracle_hifi_lens(seed, r0, n, _ptr(out, _u64p))
+        return out
+
+    def hifi_read(self, seed, r, n):
+        out = np.empty(n, dtype=np.uint8)
+        self.lib.s2k_oracle_hifi_read(seed, r, n, _ptr(out, _u8p))
+        return out
+
+    def hifi_checksums(self, seed, off, l, k, density, mode, threads=1):
+        """as synth_checksums_off for HiFi-like reads: read r = hifi_read(seed, r, off[r+1] - off[r])"""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        out = np.zeros(len(CHECKSUM_FIELDS), dtype=np.uint64)
+        self.lib.s2k_oracle_hifi_checksums(seed, _ptr(off, _u64p), len(off) - 1, l, k, density, mode, threads, _ptr(out, _u64p))
+        return {f: int(v) for f, v in zip(CHECKSUM_FIELDS, out)}
 
     def synth_bases(self, seed, first_base, n):
         out = np.empty(n, dtype=np.uint8)

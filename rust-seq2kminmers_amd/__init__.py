@@ -26,7 +26,7 @@ ABI_VERSION = 2  # include/s2k.h S2K_ABI_VERSION this mirror was written against
 ABI_SYMBOLS = [
     "s2k_trim", "s2k_density_for_bound", "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_set_host_batch", "s2k_strerror",
     "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
-    "s2k_hpc_device", "s2k_hpc_device_ex", "s2k_count_device", "s2k_partition_device", "s2k_synth_bases_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
+    "s2k_hpc_device", "s2k_hpc_device_ex", "s2k_count_device", "s2k_partition_device", "s2k_synth_bases_device", "s2k_synth_hifi_lengths", "s2k_synth_hifi_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
 ]
 
 
@@ -129,6 +129,9 @@ def load_library(path=None):
     L.s2k_count_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.s2k_partition_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
     L.s2k_synth_bases_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.s2k_synth_hifi_lengths.restype = None
+    L.s2k_synth_hifi_lengths.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.s2k_synth_hifi_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     L.s2k_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.s2k_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.s2k_timing_total.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
@@ -276,6 +279,16 @@ class Engine:
 
     def synth_bases_device(self, seed, first_base, n, d_ptr):
         self._check(self.lib.s2k_synth_bases_device(self.ctx, seed, first_base, n, C.c_void_p(d_ptr)))
+
+    def synth_hifi_lengths(self, seed, r0, n_reads):
+        """lengths of the HiFi-like synthetic reads r0 .. r0+n_reads-1 (BASELINE configs[3]); host array"""
+        out = np.empty(n_reads, dtype=np.uint64)
+        self.lib.s2k_synth_hifi_lengths(seed, r0, n_reads, C.c_void_p(out.ctypes.data))
+        return out
+
+    def synth_hifi_device(self, seed, r0, n_reads, d_read_off_ptr, d_bases_ptr):
+        """read r0+i is written at d_bases + d_read_off[i] (device pointers; read_off = prefix of synth_hifi_lengths)"""
+        self._check(self.lib.s2k_synth_hifi_device(self.ctx, seed, r0, n_reads, C.c_void_p(d_read_off_ptr), C.c_void_p(d_bases_ptr)))
 
     def run_file(self, path, l, k, density, mode=HashMode.Regular, batch_bases=256 << 20, flags=0):
         """FASTA/FASTQ file -> totals; the file mode of the reference's CLI (src/main.rs:51-83) on the GPU."""

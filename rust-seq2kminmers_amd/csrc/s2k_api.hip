@@ -1185,6 +1185,18 @@ s2k_status s2k_synth_bases_device(s2k_ctx *ctx, uint64_t seed, uint64_t first_ba
     return S2K_OK;
 }
 
+void s2k_synth_hifi_lengths(uint64_t seed, uint64_t r0, uint64_t n_reads, uint64_t *lengths) {
+    if (!lengths) return;
+    for (uint64_t i = 0; i < n_reads; i++) lengths[i] = synth_hifi_len(seed, r0 + i);
+}
+
+s2k_status s2k_synth_hifi_device(s2k_ctx *ctx, uint64_t seed, uint64_t r0, uint64_t n_reads, const uint64_t *d_read_off, uint8_t *d_bases) {
+    if (!ctx || ((!d_read_off || !d_bases) && n_reads)) return S2K_ERR_INVALID_ARG;
+    S2K_TRY(hipSetDevice(ctx->device), "set device");
+    S2K_TRY(launch_synth_hifi(seed, r0, n_reads, d_read_off, d_bases, ctx->stream), "synth hifi kernel");
+    return S2K_OK;
+}
+
 s2k_status s2k_hpc_device(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
                           uint64_t n_bases, uint64_t *d_hpc_off, uint8_t *d_hpc, uint32_t *d_pos, uint64_t capacity,
                           uint64_t *n_runs) {

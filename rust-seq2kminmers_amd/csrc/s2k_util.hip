@@ -175,6 +175,55 @@ hipError_t launch_scan_u32(const uint32_t *in, uint64_t n, uint64_t *out, uint64
     return hipGetLastError();
 }
 
+// ---- HiFi-like synthetic reads (BASELINE configs[3]) ---------------------------------------------------------
+// Read r is a sequence of homopolymer runs drawn from splitmix64 keyed by (seed, r): run lengths geometric with mean 2, ~0.1 % of
+// the runs stretched to 20..2999 bases, consecutive runs of different letters; its length is ~N(15 000, 2 000) from eight 16-bit
+// uniforms in integer arithmetic, clipped to [2 000, 30 000].  Same functions as oracle/s2k_oracle.c (s2k_oracle_hifi_len / _read).
+__host__ __device__ inline uint64_t splitmix64_hd(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline uint64_t hifi_key(uint64_t seed, uint64_t r) { return seed ^ (r * 0xA24BAED4963EE407ULL) ^ 0x9FB21C651E98DF25ULL; }
+uint64_t synth_hifi_len(uint64_t seed, uint64_t r) {
+    const uint64_t z0 = splitmix64_hd(hifi_key(seed, r) ^ 0x5851F42D4C957F2DULL), z1 = splitmix64_hd(z0);
+    int64_t s = 0;
+    for (int i = 0; i < 4; i++) s += (int64_t)((z0 >> (16 * i)) & 0xFFFF) + (int64_t)((z1 >> (16 * i)) & 0xFFFF);
+    const int64_t len = 15000 + ((s - 262140) * 2000) / 53510;
+    return (uint64_t)(len < 2000 ? 2000 : len > 30000 ? 30000 : len);
+}
+// One thread per read, runs written 16 bytes at a time where the destination is aligned (a read is a sequential process; a
+// million of them run side by side).  Test / bench scaffolding, not a hot kernel.
+__global__ __launch_bounds__(256) void synth_hifi_kernel(uint64_t seed, uint64_t r0, uint64_t n_reads, const uint64_t *__restrict__ read_off,
+                                                         uint8_t *__restrict__ d) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_reads) return;
+    const uint64_t a = read_off[i], n = read_off[i + 1] - a;
+    uint8_t *out = d + a;
+    uint64_t x = splitmix64_hd(hifi_key(seed, r0 + i));
+    uint32_t letter = 0;
+    for (uint64_t pos = 0, run = 0; pos < n; run++) {
+        x = splitmix64_hd(x);
+        uint64_t len = 1 + (uint64_t)__builtin_ctz((uint32_t)x | 0x80000000u);
+        if (((x >> 32) & 1023) == 0) len = 20 + ((x >> 42) & 0x3FFF) % 2980;
+        letter = run == 0 ? (uint32_t)(x >> 60) & 3u : (letter + 1u + (uint32_t)((x >> 56) & 15u) % 3u) & 3u;
+        const uint32_t ch = letter == 0 ? 'A' : letter == 1 ? 'C' : letter == 2 ? 'G' : 'T';
+        if (len > n - pos) len = n - pos;
+        if (len >= 48) { // long run: bytes up to the next 16-byte boundary, whole 16-byte pieces, the rest
+            const uint32_t w = ch * 0x01010101u;
+            while ((((uintptr_t)(out + pos)) & 15) && len) { out[pos++] = (uint8_t)ch; len--; }
+            for (; len >= 16; len -= 16, pos += 16) *reinterpret_cast<uint4 *>(out + pos) = make_uint4(w, w, w, w);
+        }
+        for (; len; len--) out[pos++] = (uint8_t)ch;
+    }
+}
+hipError_t launch_synth_hifi(uint64_t seed, uint64_t r0, uint64_t n_reads, const uint64_t *read_off, uint8_t *d, hipStream_t st) {
+    if (n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_hifi_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, seed, r0, n_reads, read_off, d);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d, hipStream_t st) {
     if (n == 0) return hipSuccess;
     uint64_t groups = ((first_base + n + 15) >> 4) - (first_base >> 4);

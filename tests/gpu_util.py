@@ -100,10 +100,11 @@ def folds_torch(t, n, n_reads):
 FOLD_FIELDS = ("fold_hash", "fold_start", "fold_end", "fold_rev", "fold_km_off", "fold_count")
 
 
-def sample_reads_compare(eng_out, n, oracle, seed, first_base, off_of, read_ids, l, k, d, omode, threads=8):
+def sample_reads_compare(eng_out, n, oracle, seed, first_base, off_of, read_ids, l, k, d, omode, threads=8, gen=None):
     """>= 1 % element-wise check of a full-size run: the reads `read_ids` (ascending) are regenerated on the host, run
     through the oracle, and compared field by field with the slices [km_off[r], km_off[r+1]) of the device output.
-    eng_out: dict of torch tensors; off_of(r) -> (stream offset, length) of read r."""
+    eng_out: dict of torch tensors; off_of(r) -> (stream offset, length) of read r; gen(r, length) -> the bases of read r
+    (default: the slice of the uniform synthetic stream)."""
     import torch
 
     read_ids = np.asarray(read_ids, dtype=np.int64)
@@ -112,7 +113,7 @@ def sample_reads_compare(eng_out, n, oracle, seed, first_base, off_of, read_ids,
     bases = np.empty(int(soff[-1]), dtype=np.uint8)
     for i, r in enumerate(read_ids):
         a, ln = off_of(int(r))
-        bases[int(soff[i]): int(soff[i + 1])] = oracle.synth_bases(seed, first_base + a, ln)
+        bases[int(soff[i]): int(soff[i + 1])] = gen(int(r), ln) if gen else oracle.synth_bases(seed, first_base + a, ln)
     ref = oracle.batch(bases, soff, l, k, d, omode, threads=threads)
     dev = eng_out["km_off"].device
     idx = torch.from_numpy(read_ids).to(dev)

@@ -715,6 +715,57 @@ def test_baseline_config4_hifi_like_hpc_backmap(eng, oracle):
     compare(eng, oracle, reads, 31, 10, 0.01, HM.Regular, expect_path="desc", tag="C4-hifi-regular")
 
 
+def test_full_size_config4_hifi_like_whole_run_checksums(eng, oracle):
+    """BASELINE configs[3] AT SIZE and device-resident: 1 000 000 HiFi-like reads (~15 Gbp; lengths
+    ~N(15 k, 2 k), homopolymer runs of geometric length with mean 2, ~0.1 % of the runs 20..2999 bases long, generated in HBM
+    by s2k_synth_hifi_device -- the oracle's twin, tests/test_hifi_generator.py), l=31 k=10 d=0.01, the two modes that compress
+    homopolymers (Hpc, HpcSimd) and Regular: whole-run counts / XOR / sums / order-sensitive folds against the oracle on the host
+    cores, and >= 1 % of the reads field by field (start / end are the original-space back-map of src/nthash_hpc.rs:280-281)."""
+    import os
+    import torch
+
+    n_reads, seed = 1_000_000, 3
+    lens = eng.synth_hifi_lengths(seed, 0, n_reads)
+    assert np.array_equal(lens, oracle.hifi_lengths(seed, 0, n_reads))
+    off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+    n_bases = int(off[-1])
+    assert n_bases > 14_900_000_000
+    dev = torch.device("cuda", 0)
+    d_b = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
+    d_o = torch.from_numpy(off.astype(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    eng.synth_hifi_device(seed, 0, n_reads, d_o.data_ptr(), d_b.data_ptr())
+    cap = int(n_bases * 0.0135)
+    t = {"km_off": torch.empty(n_reads + 1, dtype=torch.int64, device=dev), "hash": torch.empty(cap, dtype=torch.int64, device=dev),
+         "start": torch.empty(cap, dtype=torch.int32, device=dev), "end": torch.empty(cap, dtype=torch.int32, device=dev),
+         "rev": torch.empty(cap, dtype=torch.uint8, device=dev)}
+    o = pkg.DeviceOut()
+    o.km_capacity = cap
+    o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    for mode in (HM.Hpc, HM.HpcSimd, HM.Regular):
+        torch.cuda.synchronize()
+        c = eng.extract_device(d_b.data_ptr(), d_o.data_ptr(), n_reads, n_bases, 31, 10, 0.01, int(mode), o)
+        ref = oracle.hifi_checksums(seed, off, 31, 10, 0.01, OMODE[mode], threads=threads)
+        n = c["n_kminmers"]
+        assert c["path"] == 0 and c["n_bases"] == n_bases
+        assert (n, c["n_minimizers"], c["xor_hash"]) == (ref["n_kminmers"], ref["n_minimizers"], ref["xor_hash"]), (int(mode), c, ref)
+        assert int(t["km_off"][-1].item()) == n and bool((t["km_off"][1:] >= t["km_off"][:-1]).all())
+        assert _xor_reduce(t["hash"][:n]) == ref["xor_hash"]
+        assert int(t["start"][:n].to(torch.int64).sum().item()) == ref["sum_start"]
+        assert int(t["end"][:n].to(torch.int64).sum().item()) == ref["sum_end"]
+        assert int(t["rev"][:n].to(torch.int64).sum().item()) == ref["n_rev"]
+        assert folds_torch(t, n, n_reads) == {x: ref[x] for x in FOLD_FIELDS}, int(mode)
+        ids = spread_sample(n_reads, 0.0105, np.random.default_rng(4000 + int(mode)))
+        assert len(ids) >= n_reads // 100
+        assert sample_reads_compare(t, n, oracle, seed, 0, lambda r: (int(off[r]), int(lens[r])), ids, 31, 10, 0.01, OMODE[mode],
+                                    threads=threads, gen=lambda r, ln: oracle.hifi_read(seed, r, ln)) > 0
+        if mode == HM.Hpc:  # the long runs really widen the spans the back-map has to cover
+            assert int((t["end"][:n] - t["start"][:n]).max().item()) > 2000
+    del d_b, t
+    torch.cuda.empty_cache()
+
+
 def test_baseline_config5_mbp_contigs_sparse_density(eng, oracle):
     """BASELINE config 5: chromosome-scale 1 Mbp contigs, d = 0.001 (bound 4 294 967): one read spans >100 tiles,
     most waves emit almost nothing, k-min-mer windows span ~5 kbp = several tiles."""

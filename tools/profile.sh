@@ -53,7 +53,10 @@ for mode in ("hpc", "regular"):
         if "synth_kernel" in k or "at::native" in k or "elementwise_kernel" in k: continue  # run once per process, not per step
         fetch += f_kb * calls_per_step; write += w_kb * calls_per_step
     open(out + "/%s_pmc_summary.txt" % mode, "w").write("\n".join(lines) + "\n")
-    res[mode] = {"mode": mode, "n_bases": 10000000000, "hbm_bytes_per_step": int((2 * fetch + write) * 1024),
+    import sys
+    sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+    import bench  # kernel_source_id(): the state of the device sources these counters were collected on (bench.py refuses a stale file)
+    res[mode] = {"mode": mode, "n_bases": 10000000000, "kernel_source_id": bench.kernel_source_id(), "hbm_bytes_per_step": int((2 * fetch + write) * 1024),
                  "fetch_size_kb_per_step": fetch, "write_size_kb_per_step": write, "kernels": per_kernel,
                  "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on python3 bench.py --steps 2 --warmup 1 --mode %s --no-other-mode; "
                            "sum over all kernels of one step (input generator and torch's own kernels left out); FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE exact; collected %s" % (mode, os.popen("date -u +%Y-%m-%dT%H:%MZ").read().strip())}
