@@ -70,7 +70,10 @@ constexpr int TW = S2K_TW;                                 // waves per block = 
                                                        // tables (4 KiB once instead of three times)
 constexpr int HS_OFF = 16;                             // data starts here; byte HS_OFF-1 absorbs "slot -1" stores
 constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window slack
-constexpr int CAPP = 16;                               // positions per capture piece (8 measured in rounds 2 and 3: half the re-derivations, no gain)
+#ifndef S2K_CAPP
+#define S2K_CAPP 16
+#endif
+constexpr int CAPP = S2K_CAPP;                         // positions per capture piece: 16 or 8 (8: half the re-derivations, nine more registers)
 constexpr int NPC = TILE_T / CAPP;                     // 9 capture pieces per lane
 constexpr int MAX_L_TILED = 64;
 #ifndef S2K_LISTCAP
@@ -287,8 +290,8 @@ template <int L, int LA>
 __device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t bound, int lane, int np, uint32_t (&caps)[NPC],
                                                  uint32_t (&raw)[5]) {
     constexpr int T = TILE_T;
-    static_assert(L >= 9 && L <= 32, "the static schedule assumes 8 < l <= 32");
-    static_assert(CAPP == 16 && LA <= 8, "pieces of 16 positions");
+    static_assert(L > LA && L >= 4 && L <= 32, "the static schedule looks LA bases ahead and keeps one address register per base of the l-mer");
+    static_assert((CAPP == 16 || CAPP == 8) && LA <= 8, "capture pieces of 16 or 8 positions");
     uint32_t W[4 * ((T + L + 15) / 16)];
     const uint4 *src = reinterpret_cast<const uint4 *>(D + 16 * np * lane);
     {
@@ -319,21 +322,24 @@ __device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 
     }
     uint32_t bits = 0;
 #pragma unroll
-    for (int g = 0; g < NPC; g++) { // static piece index: caps[] and raw[] stay in registers
+    for (int g = 0; g < TILE_T / 16; g++) { // static piece index: caps[] and raw[] stay in registers
         if (g < np) {
-            uint32_t cap = 0;
-            for (int i = 0; i < CAPP; i++) {
-                const int pos = CAPP * g + i;
-                uint32_t hv = fh < rh ? fh : rh;
-                bool hit = hv <= bound;
-                cap = hit ? hv : cap;
-                bits = (bits << 1) | (hit ? 1u : 0u);
-                uint2 to = tab_out(tab, q[pos]);
-                uint2 ti = tab_in(tab, q[pos + l]);
-                fh = __builtin_rotateleft32(fh, 1) ^ to.x ^ ti.x;
-                rh = __builtin_rotateright32(rh, 1) ^ to.y ^ ti.y;
+#pragma unroll
+            for (int h = 0; h < 16 / CAPP; h++) {
+                uint32_t cap = 0;
+                for (int i = 0; i < CAPP; i++) {
+                    const int pos = 16 * g + CAPP * h + i;
+                    uint32_t hv = fh < rh ? fh : rh;
+                    bool hit = hv <= bound;
+                    cap = hit ? hv : cap;
+                    bits = (bits << 1) | (hit ? 1u : 0u);
+                    uint2 to = tab_out(tab, q[pos]);
+                    uint2 ti = tab_in(tab, q[pos + l]);
+                    fh = __builtin_rotateleft32(fh, 1) ^ to.x ^ ti.x;
+                    rh = __builtin_rotateright32(rh, 1) ^ to.y ^ ti.y;
+                }
+                caps[(16 / CAPP) * g + h] = cap;
             }
-            caps[g] = cap;
             if (g % 2 == 0) raw[g / 2] = __builtin_bitreverse32(bits) >> 16;
             else {
                 raw[g / 2] = __builtin_bitreverse32(bits);
@@ -384,7 +390,11 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
         }                                                                                \
     } while (0)
 #else
+#ifdef S2K_ISA_MARKS // analysis builds only (tools/isa/phase_hist.py): the phase boundaries as comments in the ISA
+#define S2K_STAMP(i) do { (void)ph; (void)stamp; asm volatile("; S2K_PHASE %0" ::"i"(i)); } while (0)
+#else
 #define S2K_STAMP(i) do { (void)ph; (void)stamp; } while (0)
+#endif
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -448,15 +458,29 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     const int vb = (int)tile_len - TILE_T * lane;      // valid bytes in this lane's chunk (may be <=0 or >=144)
     const bool partial = tile_len < (uint32_t)TILE_BASES;
     // 3. pass 1: SWAR "differs from its predecessor" per byte -> four flags per dword -> natural-order masks
+    uint32_t pair7 = 0;
 #pragma unroll
     for (int d = 0; d < 36; d++) {
         const uint32_t cur = c[d];
         const uint32_t prv = __builtin_amdgcn_alignbyte(cur, d == 0 ? prevw : c[d - 1], 3); // predecessor of every byte
         const uint32_t x = cur ^ prv;
         const uint32_t y = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; // 0x80 per byte that differs
-        const uint32_t nib7 = __builtin_amdgcn_udot4(y, 0x08040201u, 0u, false);     // the four flags as a nibble, times 128
-        const int sh = 4 * (d & 7) - 7; // (a constant once the loop is unrolled: one shift per dword)
-        fmk[d >> 3] |= sh >= 0 ? nib7 << (sh >= 0 ? sh : 0) : nib7 >> (sh < 0 ? -sh : 0);
+        // the four flags as a nibble: one dot product with the weights 1, 2, 4, 8 (x 128: the flags sit at bit 7); the odd dword of a
+        // pair ADDS its nibble above the even one's (weights x 16 and the accumulator operand), so that two dwords cost one shift-or
+        if ((d & 1) == 0) {
+            pair7 = __builtin_amdgcn_udot4(y, 0x08040201u, 0u, false);
+        } else {
+            pair7 = __builtin_amdgcn_udot4(y, 0x80402010u, pair7, false);
+            const int sh = 8 * ((d & 7) >> 1) - 7; // (constants once the loop is unrolled)
+            // (v_lshl_or_b32: the opaque copy keeps the compiler from re-associating the ors into a tree of separate shifts and ors.
+            // The instruction itself must stay the compiler's: on gfx950 a VALU instruction may read a v_dot4 result only three wait
+            // states after it, which the hazard recognizer cannot arrange for an instruction hidden in inline asm -- measured: wrong flags)
+            if (sh >= 0) {
+                fmk[d >> 3] = (pair7 << (sh >= 0 ? sh : 0)) | fmk[d >> 3];
+                asm("" : "+v"(fmk[d >> 3]));
+            }
+            else fmk[d >> 3] |= pair7 >> 7;
+        }
     }
     if (partial) { // only the stream's last tile: bytes past the end are no run heads
 #pragma unroll
@@ -1064,13 +1088,16 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             for (int d = 0; d < 5; d++) {
                 uint32_t wv = vm[d];
                 const uint32_t rw = raw[d];
-                const uint32_t cap_lo = caps[2 * d], cap_hi = caps[(2 * d + 1) < NPC ? 2 * d + 1 : NPC - 1]; // static indices: registers
+                constexpr int CPW = 32 / CAPP; // kept hashes per 32 positions
+                auto capw = [&](int i) { return caps[(CPW * d + i) < NPC ? CPW * d + i : NPC - 1]; }; // static indices: registers
+                const uint32_t cap0 = capw(0), cap1 = capw(1), cap2 = capw(CPW > 2 ? 2 : 0), cap3 = capw(CPW > 2 ? 3 : 1);
                 while (wv) {
                     const uint32_t bit = __builtin_ctz(wv);
                     wv &= wv - 1;
-                    // raw hits after this one inside the same 16-position piece: the kept hash is not this hit's
-                    const uint32_t later = rw & ((0xFFFFu << (bit & 16)) & ~((2u << bit) - 1u));
-                    const uint32_t hvk = (bit & 16) ? cap_hi : cap_lo;
+                    // raw hits after this one inside the same capture piece: the kept hash is not this hit's
+                    const uint32_t pm = CAPP == 16 ? (0xFFFFu << (bit & 16)) : (0xFFu << (bit & 24));
+                    const uint32_t later = rw & (pm & ~((2u << bit) - 1u));
+                    const uint32_t hvk = CAPP == 16 ? ((bit & 16) ? cap1 : cap0) : ((bit & 16) ? ((bit & 8) ? cap3 : cap2) : ((bit & 8) ? cap1 : cap0));
                     if (SINGLE || (k >= b0 && k < b0 + LISTCAP)) {
                         S.list[k - b0] = (uint16_t)((Tq * lane + 32 * d + bit) | (later ? 0x8000u : 0u));
                         if (!later && !(sem.dbg_skip & 16)) rec.hash[base + k] = hvk;

@@ -95,7 +95,7 @@ def test_ragged_batches_all_tile_alignments(eng, oracle):
 def test_l_grid_dynamic_and_static_paths(eng, oracle):
     rng = np.random.default_rng(7)
     reads = [rand_read(rng, int(n), hp=0.25, odd=0.01) for n in rng.integers(0, 30000, size=24)]
-    for l in (1, 2, 4, 5, 7, 10, 11, 12, 15, 17, 21, 25, 28, 31, 32, 33, 47, 64):  # 10, 12, 15, 17, 21, 25, 28, 31 have unrolled instantiations
+    for l in (1, 2, 4, 5, 7, 10, 11, 12, 15, 17, 21, 25, 28, 31, 32, 33, 47, 64):  # 5, 7, 10, 11, 12, 15, 17, 21, 25, 28, 31 have unrolled instantiations
         for mode in SCALAR:
             compare(eng, oracle, reads, l, 5, 0.02, mode, expect_path=0, tag="lgrid")
     for l in (65, 100, 255):  # beyond the tiled kernel: serial path
@@ -601,7 +601,7 @@ def test_full_size_config2_whole_run_checksums(eng, oracle):
 
 def test_mid_size_every_kernel_instantiation_whole_run_checksums(eng, oracle):
     """200 Mbp (21 700 tiles: more than the 3 x 3072 a launch deals statically, so the cursors of the dynamic deal are in play)
-    through every instantiation of the tiled kernel -- the unrolled l = 10, 12, 15, 17, 21, 25, 28, 31 and the run-time-l one (l = 23, 64) --
+    through every instantiation of the tiled kernel -- the unrolled l = 5, 7, 10, 11, 12, 15, 17, 21, 25, 28, 31 and the run-time-l one (l = 23, 64) --
     in all four modes, whole-run checksums against the oracle."""
     import os
     import torch
@@ -620,7 +620,7 @@ def test_mid_size_every_kernel_instantiation_whole_run_checksums(eng, oracle):
     o.km_capacity = cap
     o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
     threads = max(1, min(os.cpu_count() or 1, 64))
-    for l, d in ((10, 0.03), (12, 0.05), (15, 0.01), (17, 0.02), (21, 0.02), (23, 0.01), (25, 0.01), (28, 0.02), (31, 0.003), (64, 0.01)):
+    for l, d in ((5, 0.02), (7, 0.03), (10, 0.03), (11, 0.02), (12, 0.05), (15, 0.01), (17, 0.02), (21, 0.02), (23, 0.01), (25, 0.01), (28, 0.02), (31, 0.003), (64, 0.01)):
         for mode in (HM.Regular, HM.Hpc, HM.Simd, HM.HpcSimd):
             if l > 31 and mode in (HM.Simd, HM.HpcSimd):
                 continue  # the reference's SIMD iterators stop at l = 31
