@@ -480,14 +480,23 @@ s2k_status enqueue(s2k_ctx *ctx) {
                 S2K_TRY(hipEventRecord(ctx->chunk_ev[n_chunks], st), "event");
                 S2K_TRY(hipStreamWaitEvent(s2, ctx->chunk_ev[n_chunks], 0), "stream wait");
                 if (tm) S2K_TRY(hipEventRecord(ctx->ev[3], s2), "event");
+                // (Every minimizer kernel on the caller's stream.  A chunk boundary costs ~40 us -- the waves of a persistent launch run dry
+                // within a tile time or two of each other, then the launch and the first tile's unhidden load: 0.22 ms of 6.6 for six chunks,
+                // profiles/r04_chunk_boundaries.txt.  Alternating the chunks between two streams, so that the blocks of chunk c+1 take every
+                // CU its block of chunk c has left, was measured SLOWER, 7.30 vs 7.09 ms per step: profiles/r04_ab_tile_streams.txt.)
                 // (equal chunks: tapering the last ones -- their k-min-mer kernel is the one nothing runs beside -- measured no better)
                 for (uint32_t ch = 0; ch < n_chunks; ch++) {
                     const uint64_t T0 = n_tiles * ch / n_chunks, T1 = n_tiles * (ch + 1) / n_chunks;
+                    hipStream_t ts = st;
                     S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, T1, tile_read0, sem, rec,
-                                                   pool_cursor + (size_t)CURSOR_WORDS * ch, nullptr, nullptr, nullptr, ctx->d_counts, &dz, T0, st),
+                                                   pool_cursor + (size_t)CURSOR_WORDS * ch, nullptr, nullptr, nullptr, ctx->d_counts, &dz, T0, ts),
                             "tiled minimizer kernel");
-                    S2K_TRY(hipEventRecord(ctx->chunk_ev[ch], st), "event");
+                    S2K_TRY(hipEventRecord(ctx->chunk_ev[ch], ts), "event");
                     S2K_TRY(hipStreamWaitEvent(s2, ctx->chunk_ev[ch], 0), "stream wait");
+#ifdef S2K_DEBUG_KNOBS // S2K_DEBUG_NOKM=1: the chunked minimizer kernels alone (what do the launch boundaries cost?); results are wrong
+                    static const bool nokm = getenv("S2K_DEBUG_NOKM") != nullptr;
+                    if (nokm) continue;
+#endif
                     S2K_TRY(launch_desc_scan(T0, T1, dz, d_scan, ctx->d_counts, s2), "tile word scan");
                     S2K_TRY(launch_desc_kminmers(T0, T1, n_tiles, n_reads, dz, rec, ctx->d_counts, s2), "k-min-mer kernel");
                 }

@@ -11,6 +11,7 @@
 //     before it.  Read positions: j = (tile start + offset) - (start of the read segment), from the tile's own list of read
 //     starts; km_off (and mn_off) of the reads that start in the tile are written here too.  No per-read table is read.
 #include "s2k_dev.h"
+#include <cstdlib>
 
 namespace s2k {
 namespace {
@@ -422,10 +423,14 @@ hipError_t launch_desc_kminmers(uint64_t tile_begin, uint64_t tile_end, uint64_t
     if (tile_end <= tile_begin) return hipSuccess;
     if (dz.k == 0 || dz.k > (uint32_t)DK_KMAX || rec.slab_cap < 64) return hipErrorInvalidValue;
     const dim3 g((unsigned)((tile_end - tile_begin + DK_WAVES - 1) / DK_WAVES)), b(64 * DK_WAVES);
+    unsigned pad = 0; // unused dynamic LDS: bounds how many of these blocks fit a CU beside the persistent minimizer kernel
+#ifdef S2K_DEBUG_KNOBS
+    if (const char *e = getenv("S2K_DEBUG_KM_LDS")) pad = (unsigned)atoi(e);
+#endif
     switch (dz.k) { // the benchmark's k and the reference demo's (src/main.rs:13-48) get an unrolled window loop
-    case 10: hipLaunchKernelGGL(desc_kminmer_kernel<10>, g, b, 0, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
-    case 5: hipLaunchKernelGGL(desc_kminmer_kernel<5>, g, b, 0, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
-    default: hipLaunchKernelGGL(desc_kminmer_kernel<0>, g, b, 0, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
+    case 10: hipLaunchKernelGGL(desc_kminmer_kernel<10>, g, b, pad, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
+    case 5: hipLaunchKernelGGL(desc_kminmer_kernel<5>, g, b, pad, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
+    default: hipLaunchKernelGGL(desc_kminmer_kernel<0>, g, b, pad, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
     }
     return hipGetLastError();
 }
