@@ -127,8 +127,7 @@ class KminmersIterator { // src/lib.rs:70-131: per-read facade
 
 // The crate's minimizer iterators (re-exported at src/lib.rs:6-13), over S2K_FLAG_WANT_MINIMIZERS.  Like the reference they take
 // the u32 hash bound, not a density.  One GPU call per sequence: for throughput use Engine::extract with the flag on a batch.
-// Defined for seq.size() > l, the only way KminmersIterator constructs them (src/lib.rs:97-109); l > seq.size() throws as
-// KSizeOutOfRange does (src/nthash_hpc.rs:117-121).
+// l > seq.size() throws as KSizeOutOfRange does (src/nthash_hpc.rs:117-121); seq.size() == l is accepted as in the reference.
 struct Minimizer { // NtHashHPCIterator::Item = (start, end, hash), src/nthash_hpc.rs:193
     size_t start, end;
     uint32_t hash;
@@ -138,7 +137,20 @@ class MinimizerIterator {
   public:
     MinimizerIterator(Engine &eng, std::string_view seq, size_t l, uint32_t hash_bound) {
         if (l > seq.size()) throw Error(S2K_ERR_L_RANGE, "K size is out of range for the given sequence size"); // src/nthash_hpc.rs:19-22
-        if (seq.size() == l) throw Error(S2K_ERR_INVALID_ARG, "the minimizer iterators are reproduced for seq.len() > l (src/lib.rs:97)");
+        if (seq.size() == l) {
+            // Accepted by the reference's iterators (only l > len is KSizeOutOfRange).  The scalar Hpc iterator yields nothing then (its only
+            // l-mer is the last one, src/nthash_hpc.rs:265-267); the SIMD ones may yield the single l-mer.  The kernels follow
+            // KminmersIterator (len <= l: nothing, src/lib.rs:97), so that l-mer is computed on the GPU on the sequence plus one base
+            // that starts a new run, and only what lies inside the original sequence is kept (end_).
+            if (MODE == HashMode::Hpc) return; // empty batch
+            std::string ext(seq);
+            ext.push_back(seq.back() == 'A' ? 'C' : 'A');
+            batch_ = eng.extract(std::vector<std::string_view>{ext}, l, 1, s2k_density_for_bound(hash_bound), MODE, S2K_FLAG_WANT_MINIMIZERS);
+            const s2k_result &r = batch_.raw();
+            end_ = (r.n_minimizers >= 1 && r.mn_j[0] == 0 && r.mn_jend[0] < l) ? 1 : 0;
+            limited_ = true;
+            return;
+        }
         batch_ = eng.extract(std::vector<std::string_view>{seq}, l, 1, s2k_density_for_bound(hash_bound), MODE, S2K_FLAG_WANT_MINIMIZERS);
     }
     struct iterator {
@@ -152,11 +164,13 @@ class MinimizerIterator {
         bool operator!=(const iterator &o) const { return i != o.i; }
     };
     iterator begin() const { return iterator{&batch_.raw(), 0}; }
-    iterator end() const { return iterator{&batch_.raw(), batch_.n_minimizers()}; }
-    size_t size() const { return (size_t)batch_.n_minimizers(); }
+    iterator end() const { return iterator{&batch_.raw(), size()}; }
+    size_t size() const { return limited_ ? (size_t)end_ : (size_t)batch_.n_minimizers(); }
 
   private:
     Batch batch_;
+    uint64_t end_ = 0;     // seq.size() == l: how many of the batch's minimizers lie inside the original sequence (0 or 1)
+    bool limited_ = false;
 };
 using NtHashHPCIterator = MinimizerIterator<HashMode::Hpc>;         // src/nthash_hpc.rs:99-283: `<=`, last HPC l-mer dropped, end = last base of the last run
 using NtHashHPCSIMDIterator = MinimizerIterator<HashMode::HpcSimd>; // src/nthash_hpc_simd.rs:17-68: `<` vs f32 bound, end = start of the last run

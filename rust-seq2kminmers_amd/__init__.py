@@ -439,21 +439,34 @@ class _MinimizerTriples:
     """The crate's minimizer iterators (re-exported at src/lib.rs:6-13) over S2K_FLAG_WANT_MINIMIZERS: one GPU call per
     sequence -- the wrong granularity for throughput (use Engine.extract(..., want_minimizers=True) for batches); these
     classes exist so reference-style call sites read the same.  Like the reference they take the u32 `hash_bound`, not a
-    density.  Defined for len(seq) > l, the only way KminmersIterator constructs them (src/lib.rs:97-109); l > len(seq)
-    raises as KSizeOutOfRange does (src/nthash_hpc.rs:117-121)."""
+    density.  l > len(seq) raises as KSizeOutOfRange does (src/nthash_hpc.rs:117-121); len(seq) == l is accepted as in the reference."""
     _mode = None
 
     def __init__(self, seq, l, hash_bound, engine=None):
         a = _as_u8(seq)
         if l > len(a):
             raise S2kError(2, "K size %d is out of range for the given sequence size %d" % (l, len(a)))  # src/nthash_hpc.rs:19-22
-        if len(a) == l:
-            raise ValueError("the minimizer iterators are reproduced for seq.len() > l (src/lib.rs:97)")
         eng = engine or default_engine()
         d = float(eng.lib.s2k_density_for_bound(int(hash_bound)))
+        keep = None
+        if len(a) == l:
+            # seq.len() == l is accepted by the reference's iterators (only l > len is KSizeOutOfRange, src/nthash_hpc.rs:117-121):
+            # the scalar Hpc iterator then yields nothing (its only l-mer is the last one, dropped at :265-267); the two SIMD
+            # iterators may yield the single l-mer.  KminmersIterator never makes this call (src/lib.rs:97), and the kernels
+            # follow it (len <= l: nothing) -- so the l-mer is computed ON THE GPU on the sequence plus one base that starts a new
+            # run, and only what lies inside the original sequence is kept.
+            if self._mode == HashMode.Hpc:
+                self._j = self._jend = self._h = np.empty(0, dtype=np.uint32)
+                self._i = 0
+                return
+            a = np.concatenate((a, np.array([ord("C") if a[-1] == ord("A") else ord("A")], dtype=np.uint8)))
+            keep = l
         r = eng.extract_reads([a], l, 1, d, self._mode, want_minimizers=True)
         assert r["counts"]["hash_bound"] == int(hash_bound)
         self._j, self._jend, self._h = r["mn_j"], r["mn_jend"], r["mn_hash"]
+        if keep is not None:  # the l-mer that starts at 0 and ends inside the original sequence
+            m = (self._j == 0) & (self._jend < keep)
+            self._j, self._jend, self._h = self._j[m], self._jend[m], self._h[m]
         self._i = 0
 
     @classmethod

@@ -176,6 +176,7 @@ struct s2k_ctx {
     hipStream_t s_km = nullptr;                   // descriptor path: scan + k-min-mer kernel of chunk c run here, beside the minimizer kernel of chunk c+1
     std::vector<hipEvent_t> chunk_ev;             // fork / per-chunk / join events of that pipeline (no timing)
     uint32_t desc_chunks = 0;                     // chunks of tiles per call: 0 = default (6 for Hpc modes, 8 otherwise; S2K_DESC_CHUNKS overrides; 1 = no overlap)
+    uint32_t lookback_giveups = 0;                // HpcSimd calls that were run again because a look-back gave up; two make the pre-pass the default of the context
     bool force_full_runs = false;                 // S2K_FULL_RUNS=1 (A/B, tests): HpcSimd counts the runs of every read in a pre-pass instead of looking back from tile to tile
     bool trace = false;                           // S2K_TRACE: one line on stderr whenever a call is run again (record pool too small, a fall-back to another path)
     uint64_t host_batch = 1ull << 29;             // bases per sub-batch of s2k_extract (s2k_set_host_batch)
@@ -456,8 +457,10 @@ s2k_status enqueue(s2k_ctx *ctx) {
             dz.o_mn_jend = o.mn_jend;
             dz.o_mn_hash = o.mn_hash;
             dz.xor_shards = (unsigned long long *)ctx->d_xor;
-            // (a tile without a single hash position -- Simd modes with bound 0 -- writes no word: zero = "nothing, passes p on")
-            S2K_TRY(hipMemsetAsync(d_agg, 0, n_tiles * sizeof(unsigned long long), st), "memset tile words");
+            // Every tile writes its word (dense_phase<DESC>); the array still starts as the IDENTITY of the scan -- dep and pass set:
+            // "no minimizers, p handed on" (agg_identity, s2k_dev.h) -- so that a tile which left none would drop nothing.  (Zero is NOT
+            // the identity: it unpacks to dep = pass = false, q = 0, i.e. "a read ends here", and would cut every window spanning the tile.)
+            S2K_TRY(launch_fill_u64((unsigned long long *)d_agg, n_tiles, agg_pack(0, 0, 0, 0, true, true), st), "tile words fill");
             if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
             if (n_chunks == 1) {
                 S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, nullptr,
@@ -566,6 +569,9 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
         }
         if (h->need_runs && !c.full_runs) { // HpcSimd: a tile waited too long for the word of an earlier one (see enqueue())
             c.full_runs = true;
+            // (sticky after the second give-up of a context: waves that are not all resident -- another process on the GPU, CU masking --
+            // stay that way, and every later call would pay the bounded polls and the second run again)
+            if (++ctx->lookback_giveups >= 2) ctx->force_full_runs = true;
             if (ctx->trace) fprintf(stderr, "[s2k] re-run: a look-back for run heads gave up -> runs of every read counted first\n");
             s2k_status st = enqueue(ctx);
             if (st != S2K_OK) return st;

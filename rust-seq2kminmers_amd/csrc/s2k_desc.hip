@@ -68,6 +68,11 @@ __device__ inline AggF wave_scan_agg(AggF a, int lane, uint32_t K1) {
     }
     return a;
 }
+// The scan and k-min-mer kernels of chunk c run on the second stream while the minimizer kernel of chunk c+1 may be SETTING these flags on
+// the caller's stream (plain loads here, plain stores there).  That is benign because of three invariants, which any change must keep:
+// (1) the flags only ever go 0 -> 1 inside a call (memset per enqueue); (2) every one of them makes the host run the call again
+// (s2k_api.hip: finish()), so (3) no output of a call in which a flag was raised is ever consumed -- kernels of one chunk that disagree about
+// scan_off leave garbage states and partly written outputs, which the re-run overwrites.
 __device__ inline bool scan_off(const Counts *counts) { return counts->need_legacy || counts->need_runs || counts->bad_input || counts->pool_overflow; }
 
 // one wave per 64 entries of a level: what the 64 together do (coalesced loads, log-step scan)

@@ -252,6 +252,7 @@ hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, u
 hipError_t launch_validate_read_off(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint32_t *bad, hipStream_t st);
 
 hipError_t launch_synth(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d, hipStream_t st);
+hipError_t launch_fill_u64(unsigned long long *d, uint64_t n, unsigned long long v, hipStream_t st);
 // HiFi-like reads r0 .. r0+n_reads-1 at d + read_off[i] (read_off = prefix of synth_hifi_len), see s2k_util.hip
 uint64_t synth_hifi_len(uint64_t seed, uint64_t r);
 hipError_t launch_synth_hifi(uint64_t seed, uint64_t r0, uint64_t n_reads, const uint64_t *read_off, uint8_t *d, hipStream_t st);

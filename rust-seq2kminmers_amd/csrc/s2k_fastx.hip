@@ -437,7 +437,8 @@ s2k_status s2k_run_file(s2k_ctx *ctx, const char *path, const s2k_params *params
     };
 
     int cur = 0;
-    bool try_pack = !(params->flags & S2K_FLAG_NO_PACK2);
+    const bool may_pack = !(params->flags & S2K_FLAG_NO_PACK2);
+    int pack_pause = 0; // batches that go as text after one that did not pack (FASTQ, an N-rich or soft-masked stretch); then packing is tried again
     while (st == S2K_OK && pos < fsize) {
         const uint64_t end = find_record_start(fw, pos, pos + chunk, fastq == 1);
         const uint64_t n = end - pos;
@@ -467,10 +468,14 @@ s2k_status s2k_run_file(s2k_ctx *ctx, const char *path, const s2k_params *params
         // exceptions, and is rebuilt byte for byte in HBM before the splitter sees it.  FASTQ (half of it quality strings) does
         // not pack: after the first batch that did not, the text is staged as it is.
         hipError_t e;
+        const bool try_pack = may_pack && pack_pause == 0;
+        if (pack_pause > 0) pack_pause--;
         if (try_pack) {
             bool packed_any = false;
             e = s2k::ctx_stager(ctx).h2d_packed_fill(d.raw, n, copy_stream, from_file, &packed_any);
-            if (!packed_any && n >= (8u << 20)) try_pack = false;
+            // (a batch that did not pack -- or gave up half-way -- was read and scanned in vain: the next seven go as text, then one batch
+            // probes again, so that one soft-masked region of a chromosome does not cost the rest of the file its 4x smaller transfers)
+            if (!packed_any && n >= (8u << 20)) pack_pause = 7;
         } else {
             e = s2k::ctx_stager(ctx).h2d_fill(d.raw, n, copy_stream, from_file);
         }

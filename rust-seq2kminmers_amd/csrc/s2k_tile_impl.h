@@ -683,7 +683,10 @@ __device__ __forceinline__ uint32_t lookback_heads(const uint32_t *W, uint64_t t
             fs = stop ? __builtin_ctzll(stop) : 64; // the nearest tile known to end the chain; every tile nearer than it must be known too
             const uint64_t need = fs >= 63 ? ~0ull : ((2ull << fs) - 1ull);
             if ((valid & need) == need) break;
-            if (polls >= 4096) { // ~10 ms: hundreds of tile times
+            // (every 64th poll also looks at the flag itself: once one wave has given up the call is run again anyway, and the others
+            // need not wait out their own 4096 polls)
+            const bool anybody = (polls & 63) == 63 && __hip_atomic_load(&counts->need_runs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (polls >= 4096 || __builtin_amdgcn_readfirstlane((int)anybody)) { // ~10 ms: hundreds of tile times
                 if (lane == 0) counts->need_runs = 1;
                 dead = true;
                 return 0;

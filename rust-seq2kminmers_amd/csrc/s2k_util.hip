@@ -224,6 +224,16 @@ hipError_t launch_synth_hifi(uint64_t seed, uint64_t r0, uint64_t n_reads, const
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *__restrict__ d, uint64_t n, unsigned long long v) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = v;
+}
+hipError_t launch_fill_u64(unsigned long long *d, uint64_t n, unsigned long long v, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, n, v);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d, hipStream_t st) {
     if (n == 0) return hipSuccess;
     uint64_t groups = ((first_base + n + 15) >> 4) - (first_base >> 4);

@@ -1048,6 +1048,23 @@ def test_minimizer_iterator_facades(eng, oracle, ecoli):
         assert pkg.hash_bound(pkg.load_library().s2k_density_for_bound(b)) == b
     with pytest.raises(pkg.S2kError):
         pkg.NtHashHPCIterator(b"ACGT", 31, 1000, engine=eng)  # KSizeOutOfRange, src/nthash_hpc.rs:117-121
+    # seq.len() == l is accepted by the reference's iterators (only l > len is an error): the scalar Hpc iterator yields nothing (its only
+    # l-mer is the last one, src/nthash_hpc.rs:265-267), the SIMD ones yield the single l-mer when its hash is below the bound.  Expected
+    # values from the oracle's plain hash functions (the oracle's minimizer functions follow KminmersIterator: len <= l -> nothing).
+    for seq in (b"ACGTTGCAGTCATGCATGCAAGTCGATCGAC", b"ACGTACGTACGTACGTACGTACGTACGTACG", b"AAGTACGTACGTACGTACGTACGTACGTACG", b"ACGTACGTACGTACGTACGTACGTACGTAAA"):
+        l = len(seq)
+        a = np.frombuffer(seq, dtype=np.uint8)
+        assert list(pkg.NtHashHPCIterator.new(seq, l, 0xFFFFFFFF, engine=eng)) == []
+        h0 = int(oracle.nthash32_all(a, l)[0])
+        for bound in (0xFFFFFFFF, h0 + 1, h0, 1):
+            bs = oracle.hash_bound_simd(bound)  # (strict '<' against the bound as the SIMD path re-derives it, src/nthash_avx512_32.rs:47-48)
+            assert list(pkg.NtHashSIMDIterator.new(seq, l, bound, engine=eng)) == ([(0, h0)] if h0 < bs else []), (seq, bound)
+        hs, hp = oracle.hpc(a)
+        exp = []
+        if len(hs) == l:  # every base its own run: one HPC l-mer; end = start of the last run (src/nthash_hpc_simd.rs:64)
+            hh = int(oracle.nthash32_all(hs, l)[0])
+            exp = [(int(hp[0]), int(hp[l - 1]), hh)]
+        assert list(pkg.NtHashHPCSIMDIterator.new(seq, l, 0xFFFFFFFF, engine=eng)) == exp, seq
 
 
 def test_degenerate_batches(eng, oracle):

@@ -8,6 +8,9 @@
 #include <vector>
 
 using namespace s2k;
+#ifndef HX_BPC
+#define HX_BPC 1 // blocks per CU (more than 16 waves per CU need more than one block)
+#endif
 
 template <int L, int LA, bool HPC>
 __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void hl_kernel(uint32_t *out, uint64_t *cyc, int iters, uint32_t bound, int np, uint32_t seed) {
@@ -20,7 +23,11 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void hl_kernel(uint32_
         tab[c] = make_uint2(h, rotl32(r, L - 1));
         tab[256 + c] = make_uint2(rotl32(h, L), rotr32(r, 1));
     }
+#ifdef HX_SHARE // (occupancy experiment: more waves than tile buffers fit -- waves w and w + HX_SHARE read the same buffer)
+    WL &S = *reinterpret_cast<WL *>(smem + TABLE_BYTES + (size_t)(w % HX_SHARE) * sizeof(WL));
+#else
     WL &S = *reinterpret_cast<WL *>(smem + TABLE_BYTES + (size_t)w * sizeof(WL));
+#endif
     uint8_t *D = S.buf + HS_OFF;
     uint64_t x = seed * 0x9E3779B97F4A7C15ull + (blockIdx.x * TW + w) * 0xBF58476D1CE4E5B9ull + lane0;
     for (int i = lane0; i < TILE_BASES + 128; i += 64) {
@@ -57,31 +64,35 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void hl_kernel(uint32_
 template <int L, int LA, bool HPC>
 void run(const char *name, int n_cu, uint32_t *d_out, uint64_t *d_cyc, int np) {
     auto k = hl_kernel<L, LA, HPC>;
+#ifdef HX_SHARE
+    const int lds = TABLE_BYTES + HX_SHARE * (int)sizeof(WaveLdsT<HPC>);
+#else
     const int lds = block_lds_bytes<HPC>();
+#endif
     hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int iters = 3000;
-    hipLaunchKernelGGL(k, dim3(n_cu), dim3(64 * TW), lds, 0, d_out, d_cyc, 1000, 42949672u, np, 1u);
+    hipLaunchKernelGGL(k, dim3(n_cu * HX_BPC), dim3(64 * TW), lds, 0, d_out, d_cyc, 1000, 42949672u, np, 1u);
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k, dim3(n_cu), dim3(64 * TW), lds, 0, d_out, d_cyc, iters, 42949672u, np, 2u);
+    hipLaunchKernelGGL(k, dim3(n_cu * HX_BPC), dim3(64 * TW), lds, 0, d_out, d_cyc, iters, 42949672u, np, 2u);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     if (hipGetLastError() != hipSuccess) { printf("%s: launch failed\n", name); return; }
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    std::vector<uint64_t> h((size_t)n_cu * TW * 2);
+    std::vector<uint64_t> h((size_t)n_cu * HX_BPC * TW * 2);
     hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost);
     double avg = 0, ravg = 0;
     for (size_t i = 0; i < h.size() / 2; i++) { avg += (double)h[i]; ravg += (double)h[h.size() / 2 + i]; }
     avg /= h.size() / 2; ravg /= h.size() / 2;
     const double per_tile_wave = avg / iters;                   // cycles one wave spends on one tile's hash loop
-    const double per_tile_simd = per_tile_wave / (TW / 4.0);    // TW/4 waves share a SIMD
+    const double per_tile_simd = per_tile_wave / (TW * HX_BPC / 4.0);    // TW * HX_BPC / 4 waves share a SIMD
     const int pos = 16 * np;
     printf("%-28s np=%d  %8.0f cyc/tile/wave  %7.0f cyc/tile/SIMD  %6.2f cyc/position/SIMD  %7.3f us/tile/SIMD  (%.3f ms wall, shader clock %.0f MHz)\n", name, np, per_tile_wave,
-           per_tile_simd, per_tile_simd / pos, ravg / 100.0 / iters / (TW / 4.0), ms, avg / ravg * 100.0);
+           per_tile_simd, per_tile_simd / pos, ravg / 100.0 / iters / (TW * HX_BPC / 4.0), ms, avg / ravg * 100.0);
     fflush(stdout);
 }
 
@@ -91,9 +102,9 @@ int main() {
     const int n_cu = prop.multiProcessorCount;
     uint32_t *d_out;
     uint64_t *d_cyc;
-    hipMalloc(&d_out, (size_t)n_cu * 64 * TW * 4);
-    hipMalloc(&d_cyc, (size_t)n_cu * TW * 16);
-    printf("# hash loop alone, TW=%d waves per CU, %d CUs", TW, n_cu);
+    hipMalloc(&d_out, (size_t)n_cu * HX_BPC * 64 * TW * 4);
+    hipMalloc(&d_cyc, (size_t)n_cu * HX_BPC * TW * 16);
+    printf("# hash loop alone, %d x %d waves per CU, %d CUs", HX_BPC, TW, n_cu);
 #ifdef HX_TAG
     printf(", variant %s", HX_TAG);
 #endif
