@@ -309,34 +309,75 @@ __device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t boun
     hash_steps<L, T, LA, 0>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
 }
 
-// Same loop for a run-time l (1..64): bytes are fetched one by one from LDS.  Slower; only l values
-// without a static instantiation come here.
+// Same loop for a run-time l (1 .. 64; only l values without a static instantiation come here), unrolled like the static one.  The
+// outgoing base of position p is byte p of the lane's stream: static offsets, 16-byte pieces, one SDWA instruction per base as above.
+// The incoming base is byte p + l: the same stream read as dwords from the dword-aligned offset l & ~3 and funnel-shifted by l & 3
+// bytes (one v_alignbyte_b32 per four bases), after which its byte offsets are static too.  What the run-time l costs against a
+// compile-time one: the second SDWA instruction per position (the static loop keeps a base's table offset in a register from the step
+// it enters to the step it leaves -- l registers, l a constant) and the warm-up as a rolled loop: 10.3 instead of 9 vector
+// instructions per position.  (Round 3 fetched both bases byte by byte from LDS: 1.4x the static loop's time.)
+__device__ __forceinline__ uint32_t byte_x8_sel(uint32_t w, int b) { // b is a constant once the loops below are unrolled
+    switch (b & 3) {
+    case 0: return byte_x8<0>(w);
+    case 1: return byte_x8<1>(w);
+    case 2: return byte_x8<2>(w);
+    default: return byte_x8<3>(w);
+    }
+}
 __device__ __forceinline__ void hash_loop_dynamic(const uint8_t *D, const uint2 *__restrict__ tab, uint32_t bound, int lane,
                                                   uint32_t l, int np, uint32_t (&caps)[NPC], uint32_t (&raw)[5]) {
+    constexpr int T = TILE_T, NP = TILE_T / 16;
     const uint8_t *q = D + 16 * np * lane;
     uint32_t fh = 0, rh = 0;
-    for (uint32_t i = 0; i < l; i++) {
+    for (uint32_t i = 0; i < l; i++) { // first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174)
         uint2 ti = tab_in(tab, q[i]);
         fh = __builtin_rotateleft32(fh, 1) ^ ti.x;
         rh = __builtin_rotateright32(rh, 1) ^ ti.y;
     }
+    const uint4 *src = reinterpret_cast<const uint4 *>(q);
+    const uint32_t *rin = reinterpret_cast<const uint32_t *>(q + (l & ~3u));
+    const uint32_t lb = l & 3u;
+    uint32_t Wo[4 * NP], Wi[4 * NP + 4], R[4 * NP + 5];
+    auto load_out = [&](int g) { // piece g of the outgoing stream
+        const uint4 v = src[g];
+        Wo[4 * g] = v.x; Wo[4 * g + 1] = v.y; Wo[4 * g + 2] = v.z; Wo[4 * g + 3] = v.w;
+    };
+    auto load_in = [&](int g) { // piece g of the incoming stream: dwords 4g+1 .. 4g+4 of the aligned read, shifted into place
+#pragma unroll
+        for (int j = 1; j <= 4; j++) R[4 * g + j] = rin[4 * g + j];
+#pragma unroll
+        for (int j = 0; j < 4; j++) Wi[4 * g + j] = __builtin_amdgcn_alignbyte(R[4 * g + j + 1], R[4 * g + j], lb);
+    };
+    R[0] = rin[0];
+    load_out(0);
+    load_in(0);
+    load_out(1);
+    load_in(1);
+    uint2 eo = seed_pair<2048>(byte_x8<0>(Wo[0])), ei = seed_pair<0>(byte_x8<0>(Wi[0])); // seeds of position 0
     uint32_t bits = 0;
 #pragma unroll
-    for (int g = 0; g < TILE_T / 16; g++) { // static piece index: caps[] and raw[] stay in registers
-        if (g < np) {
+    for (int g = 0; g < NP; g++) {
+        if (g < np) { // wave-uniform: the (compacted) tile may be shorter than 144 bases per lane
+            if (g + 2 < NP) load_out(g + 2);
+            if (g + 2 < NP) load_in(g + 2);
 #pragma unroll
             for (int h = 0; h < 16 / CAPP; h++) {
                 uint32_t cap = 0;
+#pragma unroll
                 for (int i = 0; i < CAPP; i++) {
-                    const int pos = 16 * g + CAPP * h + i;
-                    uint32_t hv = fh < rh ? fh : rh;
-                    bool hit = hv <= bound;
-                    cap = hit ? hv : cap;
-                    bits = (bits << 1) | (hit ? 1u : 0u);
-                    uint2 to = tab_out(tab, q[pos]);
-                    uint2 ti = tab_in(tab, q[pos + l]);
-                    fh = __builtin_rotateleft32(fh, 1) ^ to.x ^ ti.x;
-                    rh = __builtin_rotateright32(rh, 1) ^ to.y ^ ti.y;
+                    const int P = 16 * g + CAPP * h + i;
+                    __builtin_amdgcn_sched_barrier(0); // (as in the static loop: keep later positions' look-ups where they are)
+                    uint2 eo_n = eo, ei_n = ei;
+                    if (P + 1 < T) { // the next position's seeds, one step ahead of their use
+                        eo_n = seed_pair<2048>(byte_x8_sel(Wo[(P + 1) >> 2], P + 1));
+                        ei_n = seed_pair<0>(byte_x8_sel(Wi[(P + 1) >> 2], P + 1));
+                    }
+                    const uint32_t hv = fh < rh ? fh : rh;                    // canonical (src/nthash_hpc.rs:276)
+                    hit_track(hv, bound, cap, bits);                          // hv <= bound (src/nthash_hpc.rs:277 / src/lib.rs:228)
+                    fh = xor3(__builtin_rotateleft32(fh, 1), eo.x, ei.x);     // src/nthash_hpc.rs:245
+                    rh = xor3(__builtin_rotateright32(rh, 1), eo.y, ei.y);    // src/nthash_hpc.rs:247-249
+                    eo = eo_n;
+                    ei = ei_n;
                 }
                 caps[(16 / CAPP) * g + h] = cap;
             }

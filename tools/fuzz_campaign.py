@@ -20,7 +20,7 @@ if not engines: engines.append(pkg.Engine(0))
 oracle = so.get()
 bad = 0; t0 = time.time()
 for it in range(iters):
-    l = int(rng.choice([31, 31, 31, 4, 5, 10, 12, 15, 16, 17, 20, 21, 25, 28, 31, 32, 33, 40, 63, 64, 65, 80]))
+    l = int(rng.choice([31, 31, 31, 4, 5, 7, 10, 11, 12, 15, 16, 17, 20, 21, 25, 28, 31, 32, 33, 40, 63, 64, 65, 80]))
     k = int(rng.choice([1, 2, 3, 5, 10, 17, 40]))
     d = float(rng.choice([0.001, 0.003, 0.01, 0.02, 0.1, 0.5, 1.0]))
     shape = int(rng.integers(0, 5))
