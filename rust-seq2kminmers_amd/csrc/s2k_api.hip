@@ -489,7 +489,15 @@ s2k_status enqueue(s2k_ctx *ctx) {
                 // CU its block of chunk c has left, was measured SLOWER, 7.30 vs 7.09 ms per step: profiles/r04_ab_tile_streams.txt.)
                 // (equal chunks: tapering the last ones -- their k-min-mer kernel is the one nothing runs beside -- measured no better)
                 for (uint32_t ch = 0; ch < n_chunks; ch++) {
-                    const uint64_t T0 = n_tiles * ch / n_chunks, T1 = n_tiles * (ch + 1) / n_chunks;
+                    // chunk boundaries: equal chunks, or (S2K_DESC_TAIL = fraction of the tiles in the LAST chunk, whose k-min-mer stage nothing
+                    // runs beside) the chunks before it share the rest equally
+                    auto cut = [&](uint32_t i) -> uint64_t {
+                        static const double tail = getenv("S2K_DESC_TAIL") ? atof(getenv("S2K_DESC_TAIL")) : 0.0;
+                        if (i >= n_chunks) return n_tiles;
+                        if (tail <= 0.0 || tail >= 1.0 || n_chunks < 2) return n_tiles * i / n_chunks;
+                        return (uint64_t)((double)n_tiles * (1.0 - tail) * (double)i / (double)(n_chunks - 1));
+                    };
+                    const uint64_t T0 = cut(ch), T1 = cut(ch + 1);
                     hipStream_t ts = st;
                     S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, T1, tile_read0, sem, rec,
                                                    pool_cursor + (size_t)CURSOR_WORDS * ch, nullptr, nullptr, nullptr, ctx->d_counts, &dz, T0, ts),
