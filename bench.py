@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["c2", "ont", "hifi"], default="c2")
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default 1 000 000 for c2, 1 250 000 for ont)")
     ap.add_argument("--read-len", type=int, default=10_000, help="c2: read length")
