@@ -35,6 +35,7 @@ extern "C" {
  * are NULL when their count is 0; device-resident read tables are validated on the device (S2K_ERR_INVALID_ARG /
  * S2K_ERR_READ_TOO_LONG from s2k_extract_device, s2k_sync and s2k_hpc_device*); S2K_ERR_NON_ASCII is no longer returned;
  * + s2k_trim, s2k_density_for_bound, S2K_FLAG_LEGACY_PATH; s2k_counts.path tells the descriptor path (0) from the legacy one (2).
+ * (Round 4 only ADDED two benchmark helpers, s2k_synth_hifi_lengths / s2k_synth_hifi_device: no existing entry point or struct changed, the version stays 2.)
  * A binding must refuse a library whose s2k_abi_version() differs from the header it was built against. */
 #define S2K_ABI_VERSION 2
 
