@@ -13,8 +13,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(extra, tmp, tag):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "ont", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+def run_bench(extra, tmp, tag, workload="ont"):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
            "--no-other-mode", "--verify-reads", "50", "--dump-shard", os.path.join(tmp, tag)] + extra
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
@@ -44,6 +44,24 @@ def test_two_ranks_equal_unsharded(tmp_path):
     a = np.load(os.path.join(tmp, "one.rank0.npz"))
     parts = [np.load(os.path.join(tmp, "two.rank%d.npz" % r)) for r in range(2)]
     assert int(parts[0]["first_base"]) == 0 and int(parts[1]["first_base"]) == int(parts[0]["n_bases"])  # contiguous shards of one stream
+    for f in ("hash", "start", "end", "rev"):
+        assert (np.concatenate([p[f] for p in parts]) == a[f]).all(), f
+    km = np.concatenate([parts[0]["km_off"][:-1], parts[1]["km_off"] + parts[0]["km_off"][-1]])
+    assert (km == a["km_off"]).all()
+
+
+@pytest.mark.gpu
+def test_hifi_workload_two_ranks_equal_one(tmp_path):
+    """BASELINE configs[3] under the multi-GPU launcher: rank r generates and processes the HiFi-like reads r * n .. (r + 1) * n - 1 of the
+    one numbered sequence of reads (weak scaling), so two ranks of 2000 reads together produce exactly what one rank of 4000 does."""
+    tmp = str(tmp_path)
+    one = run_bench(["--gpus", "1", "--reads", "4000"], tmp, "h1", workload="hifi")
+    two = run_bench(["--gpus", "2", "--reads", "2000", "--single-device", "--backend", "gloo"], tmp, "h2", workload="hifi")
+    assert one["config"]["name"] == two["config"]["name"] == "BASELINE configs[3]"
+    assert one["verified_vs_oracle"]["ok"] and two["verified_vs_oracle"]["ok"]
+    assert {k: one["counts"][k] for k in ("bases", "minimizers", "kminmers")} == {k: two["counts"][k] for k in ("bases", "minimizers", "kminmers")}
+    a = np.load(os.path.join(tmp, "h1.rank0.npz"))
+    parts = [np.load(os.path.join(tmp, "h2.rank%d.npz" % r)) for r in range(2)]
     for f in ("hash", "start", "end", "rev"):
         assert (np.concatenate([p[f] for p in parts]) == a[f]).all(), f
     km = np.concatenate([parts[0]["km_off"][:-1], parts[1]["km_off"] + parts[0]["km_off"][-1]])
