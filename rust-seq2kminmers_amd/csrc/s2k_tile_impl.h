@@ -236,10 +236,23 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * (
                                            uint2 (&EI)[T + L], uint2 (&EO)[T], uint32_t &fh, uint32_t &rh, uint32_t (&caps)[NPC], uint32_t (&raw)[5],
                                            uint32_t &bits, uint32_t bound, int np) {
     if constexpr (S < T + L - 1) {
+#ifdef HX_PIECE4 // (tools/experiments/hash_stream_bench.hip only: four pieces = 64 bytes per lane at a time, so that a lane's loads of one 128-byte line follow each other)
+        if constexpr (S % 64 == 0) {
+#pragma unroll
+            for (int pj = 0; pj < 4; pj++) {
+                constexpr int PB = S / 16 + 4;
+                if (PB + pj < (T + L + 15) / 16) {
+                    const uint4 v = src[PB + pj];
+                    W[4 * (PB + pj)] = v.x; W[4 * (PB + pj) + 1] = v.y; W[4 * (PB + pj) + 2] = v.z; W[4 * (PB + pj) + 3] = v.w;
+                }
+            }
+        }
+#else
         if constexpr (S % 16 == 0 && S / 16 + 2 < (T + L + 15) / 16) { // piece S/16+2: its first base enters >= 16 steps from now
             const uint4 v = src[S / 16 + 2];
             W[4 * (S / 16 + 2)] = v.x; W[4 * (S / 16 + 2) + 1] = v.y; W[4 * (S / 16 + 2) + 2] = v.z; W[4 * (S / 16 + 2) + 3] = v.w;
         }
+#endif
         // seeds are fetched LA steps ahead of their use, a group of LA at a time
         if constexpr (S % LA == 0) {
             __builtin_amdgcn_sched_barrier(0); // keep the scheduler from hoisting later groups' look-ups (register pressure)
@@ -298,6 +311,11 @@ __device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t boun
         const uint4 v0 = src[0], v1 = src[1];
         W[0] = v0.x; W[1] = v0.y; W[2] = v0.z; W[3] = v0.w;
         W[4] = v1.x; W[5] = v1.y; W[6] = v1.z; W[7] = v1.w;
+#ifdef HX_PIECE4
+        const uint4 v2 = src[2], v3 = src[3];
+        W[8] = v2.x; W[9] = v2.y; W[10] = v2.z; W[11] = v2.w;
+        W[12] = v3.x; W[13] = v3.y; W[14] = v3.z; W[15] = v3.w;
+#endif
     }
     uint32_t A[T + L]; // LDS byte offset of each base's table entries: formed when the base enters, reused when it leaves
     uint2 EI[T + L], EO[T];
