@@ -230,8 +230,8 @@ size_t scan_tmp_bytes(uint64_t n);
 // encode_rle (src/hpc.rs:7-25) collapses a repeated character only if it is one of "ACTGactgNn" (src/hpc.rs:14); hpc and
 // encode_rle_simd collapse any repeated byte.  `rle` selects the former in the standalone HPC kernels.
 __host__ __device__ inline bool is_rle_char(uint32_t c) {
-    const uint32_t u = c & 0xDFu; // fold case
-    return u == 'A' || u == 'C' || u == 'G' || u == 'T' || u == 'N';
+    const uint32_t d = (c & 0xDFu) - 'A'; // fold case; A C G N T are letters 0, 2, 6, 13, 19: one bit set each in a 20-bit mask
+    return d < 20u && ((0x82045u >> d) & 1u) != 0u;
 }
 __host__ __device__ inline bool run_head(uint32_t cur, uint32_t prev, bool rle) { return cur != prev || (rle && !is_rle_char(cur)); }
 
@@ -244,8 +244,9 @@ hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off
 // Standalone homopolymer compression, segment-parallel (s2k_hpc_seg.hip): the compressed bytes and read-relative run
 // starts of the whole batch, given hpc_off (= prefix of runs[]), blk_off and read_c0 from launch_read_run_counts.
 hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
-                               const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint8_t *o_hpc,
+                               const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint32_t *seg_read0, uint8_t *o_hpc,
                                uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle = false);
+size_t hpc_segment_index_words(uint64_t n_bases); // uint32 words of seg_read0 (workspace: the read that holds every segment's first byte)
 
 // read_off[0] == 0, non-decreasing, read_off[n_reads] == n_bases, no read longer than 2^32 - 2: anything else sets BAD_*
 // bits in *bad (a device word); the kernels that follow in the stream look at it and do nothing when it is set

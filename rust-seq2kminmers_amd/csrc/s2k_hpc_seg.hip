@@ -14,26 +14,50 @@ namespace {
 constexpr int HS_THREADS = 256;
 constexpr uint32_t HS_SEG = HS_THREADS * 16;
 
+// seg_read0[s] = last read r with read_off[r] <= s * HS_SEG (non-empty by construction): one thread per segment.  (Round 3 let
+// thread 0 of every block do this search -- twenty dependent global loads in front of everything the block does, 85 % of the
+// pipeline's time in that kernel.)
+__global__ __launch_bounds__(256) void hpc_segment_index_kernel(const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_segs,
+                                                                uint32_t *__restrict__ seg_read0) {
+    const uint64_t sidx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= n_segs) return;
+    const uint64_t seg = sidx * HS_SEG;
+    uint64_t lo = 0, hi = n_reads - 1;
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (read_off[mid] <= seg) lo = mid;
+        else hi = mid - 1;
+    }
+    seg_read0[sidx] = (uint32_t)lo;
+}
+
+// inclusive sum / max scans over the 64 lanes of a wave (log steps of shuffles)
+__device__ inline void wave_scan_sum_max(uint32_t &s, uint32_t &m, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t a = (uint32_t)__shfl_up((int)s, d), b = (uint32_t)__shfl_up((int)m, d);
+        if (lane >= d) {
+            s += a;
+            m = m > b ? m : b;
+        }
+    }
+}
+
 __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
     const uint8_t *__restrict__ s, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
     const uint64_t *__restrict__ hpc_off, const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ read_c0,
-    uint8_t *__restrict__ o_hpc, uint32_t *__restrict__ o_pos, uint64_t capacity, bool rle) {
+    const uint32_t *__restrict__ seg_read0, uint8_t *__restrict__ o_hpc, uint32_t *__restrict__ o_pos, uint64_t capacity, bool rle) {
     __shared__ uint32_t starts[HS_SEG / 32]; // bit i: a non-empty read starts at seg + i
-    __shared__ uint32_t ls[HS_THREADS], lm[HS_THREADS];
+    __shared__ uint32_t ws[HS_THREADS / 64], wm[HS_THREADS / 64];
     __shared__ uint32_t out_p[HS_SEG];
-    __shared__ uint8_t out_b[HS_SEG];
+    __shared__ __attribute__((aligned(16))) uint8_t out_b[HS_SEG + 16];
     __shared__ uint64_t sh_r, sh_g, sh_start;
     const int t = threadIdx.x;
     const uint64_t seg = (uint64_t)blockIdx.x * HS_SEG, seg_end = seg + HS_SEG;
     if (t < (int)(HS_SEG / 32)) starts[t] = 0;
     if (t == 0) {
-        // read that contains the first byte of the segment: last r with read_off[r] <= seg (non-empty by construction)
-        uint64_t lo = 0, hi = n_reads - 1;
-        while (lo < hi) {
-            const uint64_t mid = lo + (hi - lo + 1) / 2;
-            if (read_off[mid] <= seg) lo = mid;
-            else hi = mid - 1;
-        }
+        // read that contains the first byte of the segment (hpc_segment_index_kernel)
+        const uint64_t lo = seg_read0[blockIdx.x];
         const uint64_t a = read_off[lo];
         uint64_t g = hpc_off[lo];
         if (seg > a) { // runs of that read before the segment
@@ -86,57 +110,78 @@ __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
         prev = j < nval ? c[j] : prev;
     }
     const uint32_t last_start = sb ? (uint32_t)(16 * t + (31 - __clz(sb)) + 1) : 0u; // segment-relative + 1
-    // block-wide exclusive sum of head counts and exclusive max of start positions
-    ls[t] = __popc(heads);
-    lm[t] = last_start;
-    __syncthreads();
-#pragma unroll
-    for (int d = 1; d < HS_THREADS; d <<= 1) {
-        uint32_t a = 0, b = 0;
-        if (t >= d) {
-            a = ls[t - d];
-            b = lm[t - d];
-        }
-        __syncthreads();
-        if (t >= d) {
-            ls[t] += a;
-            lm[t] = lm[t] > b ? lm[t] : b;
-        }
-        __syncthreads();
+    // block-wide exclusive sum of head counts and exclusive max of start positions: a scan inside every wave, then the four wave totals
+    uint32_t isum = __popc(heads), imax = last_start;
+    const int lane = t & 63, wv = t >> 6;
+    wave_scan_sum_max(isum, imax, lane);
+    if (lane == 63) {
+        ws[wv] = isum;
+        wm[wv] = imax;
     }
-    // compact into LDS first, then write whole lines: the outputs of a segment are one contiguous range
-    uint32_t slot = t ? ls[t - 1] : 0u; // segment-relative
-    const uint32_t total = ls[HS_THREADS - 1];
-    const uint32_t carry = t ? lm[t - 1] : 0u;
+    __syncthreads();
+    uint32_t wsum = 0, wmax = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < HS_THREADS / 64; i++) {
+        if (i < wv) {
+            wsum += ws[i];
+            wmax = wmax > wm[i] ? wmax : wm[i];
+        }
+        total += ws[i];
+    }
+    // exclusive values of this thread: the inclusive ones of the lane before it (or of the waves before)
+    uint32_t esum = (uint32_t)__shfl_up((int)isum, 1), emax = (uint32_t)__shfl_up((int)imax, 1);
+    if (lane == 0) esum = 0, emax = 0;
+    esum += wsum;
+    emax = emax > wmax ? emax : wmax;
+    // compact into LDS first, then write whole lines: the outputs of a segment are one contiguous range.  The bytes are staged
+    // at the alignment they will have in o_hpc (g mod 4), so that the copy below moves aligned dwords on both sides.
+    const uint64_t g = sh_g;
+    const uint32_t mis = (uint32_t)(((uintptr_t)o_hpc + g) & 3u);
+    uint32_t slot = esum; // segment-relative
+    const uint32_t carry = emax;
     uint64_t cur = carry ? seg + carry - 1 : sh_start; // start of the read the current byte belongs to
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         if ((sb >> j) & 1) cur = q0 + j;
         if ((heads >> j) & 1) {
-            out_b[slot] = (uint8_t)c[j];
+            out_b[mis + slot] = (uint8_t)c[j];
             out_p[slot] = (uint32_t)(q0 + j - cur);
             slot++;
         }
     }
     __syncthreads();
-    const uint64_t g = sh_g;
-    for (uint32_t i = t; i < total; i += HS_THREADS) {
-        if (g + i < capacity) {
-            if (o_hpc) o_hpc[g + i] = out_b[i];
-            if (o_pos) o_pos[g + i] = out_p[i];
+    const uint64_t room = g < capacity ? capacity - g : 0;
+    const uint32_t n_out = total < room ? total : (uint32_t)room; // (a too small output: what fits is written, the caller is told)
+    if (o_pos)
+        for (uint32_t i = t; i < n_out; i += HS_THREADS) o_pos[g + i] = out_p[i];
+    if (o_hpc && n_out) {
+        // bytes [g, g + n_out): a head of < 4 bytes up to the first aligned dword, whole dwords, a tail of < 4 bytes
+        uint8_t *dst = o_hpc + g - mis; // 4-byte aligned; staged byte k belongs at dst[k], k in [mis, mis + n_out)
+        const uint32_t lo_b = mis, hi_b = mis + n_out;
+        const uint32_t first_dw = (lo_b + 3) >> 2, end_dw = hi_b >> 2;
+        if (first_dw < end_dw) {
+            for (uint32_t d = first_dw + t; d < end_dw; d += HS_THREADS)
+                reinterpret_cast<uint32_t *>(dst)[d] = reinterpret_cast<const uint32_t *>(out_b)[d];
+            if ((uint32_t)t < 4 * first_dw - lo_b) dst[lo_b + t] = out_b[lo_b + t];
+            if ((uint32_t)t < hi_b - 4 * end_dw) dst[4 * end_dw + t] = out_b[4 * end_dw + t];
+        } else { // fewer than one aligned dword
+            if ((uint32_t)t < n_out) dst[lo_b + t] = out_b[lo_b + t];
         }
     }
 }
 
 } // namespace
 
+size_t hpc_segment_index_words(uint64_t n_bases) { return (size_t)((n_bases + HS_SEG - 1) / HS_SEG) + 1; }
+
 hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
-                               const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint8_t *o_hpc,
-                               uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle) {
+                               const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint32_t *seg_read0 /* hpc_segment_index_words */,
+                               uint8_t *o_hpc, uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle) {
     if (n_reads == 0 || n_bases == 0) return hipSuccess;
     const uint64_t segs = (n_bases + HS_SEG - 1) / HS_SEG;
+    hipLaunchKernelGGL(hpc_segment_index_kernel, dim3((unsigned)((segs + 255) / 256)), dim3(256), 0, st, read_off, n_reads, segs, seg_read0);
     hipLaunchKernelGGL(hpc_segment_kernel, dim3((unsigned)segs), dim3(HS_THREADS), 0, st, bases, read_off, n_reads, n_bases,
-                       hpc_off, blk_off, read_c0, o_hpc, o_pos, capacity, rle);
+                       hpc_off, blk_off, read_c0, seg_read0, o_hpc, o_pos, capacity, rle);
     return hipGetLastError();
 }
 
