@@ -1254,7 +1254,7 @@ s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_
     Arena a{nullptr, 0, 0};
     uint32_t *cnt = nullptr, *blk_cnt = nullptr;
     uint64_t *tmp = nullptr, *blk_off = nullptr, *blk_tmp = nullptr, *read_c0 = nullptr;
-    uint32_t *seg_read0 = nullptr;
+    uint32_t *seg_index = nullptr;
     for (int pass = 0; pass < 2; pass++) {
         a.off = 0;
         cnt = a.take<uint32_t>(n_reads + 1);
@@ -1264,7 +1264,7 @@ s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_
             blk_off = a.take<uint64_t>(nblk + 2);
             blk_tmp = a.take<uint64_t>(scan_tmp_bytes(nblk) / sizeof(uint64_t) + 1);
             read_c0 = a.take<uint64_t>(n_reads + 1);
-            seg_read0 = a.take<uint32_t>(hpc_segment_index_words(n_bases));
+            seg_index = a.take<uint32_t>(hpc_segment_index_words(n_bases));
         }
         if (pass == 0) {
             S2K_TRY(ctx->ws.ensure(a.off + 256), "workspace allocation");
@@ -1276,7 +1276,7 @@ s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_
                 "run count kernels");
         S2K_TRY(launch_scan_u32(cnt, n_reads, d_hpc_off, tmp, 0, ctx->stream), "scan");
         if (d_hpc || d_pos)
-            S2K_TRY(launch_hpc_segments(d_bases, d_read_off, n_reads, n_bases, d_hpc_off, blk_off, read_c0, seg_read0, d_hpc, d_pos, capacity,
+            S2K_TRY(launch_hpc_segments(d_bases, d_read_off, n_reads, n_bases, d_hpc_off, blk_off, read_c0, seg_index, d_hpc, d_pos, capacity,
                                         ctx->stream, rle),
                     "hpc segment kernel");
     } else {

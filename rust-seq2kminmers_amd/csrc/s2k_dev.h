@@ -244,9 +244,9 @@ hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off
 // Standalone homopolymer compression, segment-parallel (s2k_hpc_seg.hip): the compressed bytes and read-relative run
 // starts of the whole batch, given hpc_off (= prefix of runs[]), blk_off and read_c0 from launch_read_run_counts.
 hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
-                               const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint32_t *seg_read0, uint8_t *o_hpc,
+                               const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint32_t *seg_index, uint8_t *o_hpc,
                                uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle = false);
-size_t hpc_segment_index_words(uint64_t n_bases); // uint32 words of seg_read0 (workspace: the read that holds every segment's first byte)
+size_t hpc_segment_index_words(uint64_t n_bases); // uint32 words of seg_index (8-byte aligned workspace: per segment its first output slot, the read that holds its first byte and where that read starts)
 
 // read_off[0] == 0, non-decreasing, read_off[n_reads] == n_bases, no read longer than 2^32 - 2: anything else sets BAD_*
 // bits in *bad (a device word); the kernels that follow in the stream look at it and do nothing when it is set

@@ -14,13 +14,17 @@ namespace {
 constexpr int HS_THREADS = 256;
 constexpr uint32_t HS_SEG = HS_THREADS * 16;
 
-// seg_read0[s] = last read r with read_off[r] <= s * HS_SEG (non-empty by construction): one thread per segment.  (Round 3 let
-// thread 0 of every block do this search -- twenty dependent global loads in front of everything the block does, 85 % of the
-// pipeline's time in that kernel.)
-__global__ __launch_bounds__(256) void hpc_segment_index_kernel(const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_segs,
-                                                                uint32_t *__restrict__ seg_read0) {
+// Per-segment index, one thread per segment (and one entry past the last): seg_read0[s] = last read r with read_off[r] <= s * HS_SEG
+// (non-empty by construction), seg_a[s] = where that read starts, seg_g[s] = output slot of the segment's first run head (hpc_off of
+// that read + its runs before the segment, from the two prefixes of launch_read_run_counts).  (Round 3 let thread 0 of every block
+// do the search and the dependent loads behind it -- five round trips to memory in front of everything the block does, 85 % of the
+// pipeline's time in that kernel; now a block starts with three scalar loads.)
+__global__ __launch_bounds__(256) void hpc_segment_index_kernel(const uint8_t *__restrict__ s, const uint64_t *__restrict__ read_off, uint64_t n_reads,
+                                                                uint64_t n_segs, const uint64_t *__restrict__ hpc_off, const uint64_t *__restrict__ blk_off,
+                                                                const uint64_t *__restrict__ read_c0, uint64_t *__restrict__ seg_g,
+                                                                uint64_t *__restrict__ seg_a, uint32_t *__restrict__ seg_read0, bool rle) {
     const uint64_t sidx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (sidx >= n_segs) return;
+    if (sidx > n_segs) return;
     const uint64_t seg = sidx * HS_SEG;
     uint64_t lo = 0, hi = n_reads - 1;
     while (lo < hi) {
@@ -29,6 +33,15 @@ __global__ __launch_bounds__(256) void hpc_segment_index_kernel(const uint64_t *
         else hi = mid - 1;
     }
     seg_read0[sidx] = (uint32_t)lo;
+    if (sidx == n_segs) return; // (the entry past the last segment only bounds the reads that start inside the last one)
+    const uint64_t a = read_off[lo];
+    uint64_t g = hpc_off[lo];
+    if (seg > a) { // runs of that read before the segment
+        const bool neq_a = a == 0 || run_head(s[a], s[a - 1], rle);
+        g += blk_off[seg / 256] - read_c0[lo] + (neq_a ? 0u : 1u);
+    }
+    seg_g[sidx] = g;
+    seg_a[sidx] = a;
 }
 
 // inclusive sum / max scans over the 64 lanes of a wave (log steps of shuffles)
@@ -45,64 +58,50 @@ __device__ inline void wave_scan_sum_max(uint32_t &s, uint32_t &m, int lane) {
 
 __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
     const uint8_t *__restrict__ s, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
-    const uint64_t *__restrict__ hpc_off, const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ read_c0,
-    const uint32_t *__restrict__ seg_read0, uint8_t *__restrict__ o_hpc, uint32_t *__restrict__ o_pos, uint64_t capacity, bool rle) {
+    const uint64_t *__restrict__ seg_g, const uint64_t *__restrict__ seg_a, const uint32_t *__restrict__ seg_read0, uint8_t *__restrict__ o_hpc,
+    uint32_t *__restrict__ o_pos, uint64_t capacity, bool rle) {
     __shared__ uint32_t starts[HS_SEG / 32]; // bit i: a non-empty read starts at seg + i
     __shared__ uint32_t ws[HS_THREADS / 64], wm[HS_THREADS / 64];
     __shared__ uint32_t out_p[HS_SEG];
     __shared__ __attribute__((aligned(16))) uint8_t out_b[HS_SEG + 16];
-    __shared__ uint64_t sh_r, sh_g, sh_start;
     const int t = threadIdx.x;
     const uint64_t seg = (uint64_t)blockIdx.x * HS_SEG, seg_end = seg + HS_SEG;
-    if (t < (int)(HS_SEG / 32)) starts[t] = 0;
-    if (t == 0) {
-        // read that contains the first byte of the segment (hpc_segment_index_kernel)
-        const uint64_t lo = seg_read0[blockIdx.x];
-        const uint64_t a = read_off[lo];
-        uint64_t g = hpc_off[lo];
-        if (seg > a) { // runs of that read before the segment
-            const bool neq_a = a == 0 || run_head(s[a], s[a - 1], rle);
-            g += blk_off[seg / 256] - read_c0[lo] + (neq_a ? 0u : 1u);
-        }
-        sh_r = lo;
-        sh_g = g;
-        sh_start = a;
-    }
-    __syncthreads();
-    const uint64_t r_s = sh_r;
-    // starts of the non-empty reads inside the segment (read r_s itself when it starts exactly here)
-    for (uint64_t i = (read_off[r_s] == seg ? 0 : 1) + (uint64_t)t;; i += HS_THREADS) {
-        const uint64_t r = r_s + i;
-        bool more = false;
-        if (r < n_reads) {
-            const uint64_t a = read_off[r];
-            if (a < seg_end) {
-                more = true;
-                if (a >= seg && read_off[r + 1] > a) atomicOr(&starts[(a - seg) >> 5], 1u << ((a - seg) & 31));
-            }
-        }
-        if (!__syncthreads_or(more)) break;
-    }
-    __syncthreads();
-    // this thread's 16 bytes
+    // block-uniform (scalar loads): the read that contains the first byte of the segment, the last read that starts at or before
+    // the end of the segment, the segment's first output slot
+    const uint64_t r_s = seg_read0[blockIdx.x], r_e = seg_read0[blockIdx.x + 1];
+    const uint64_t g = seg_g[blockIdx.x], a_s = seg_a[blockIdx.x];
+    // this thread's 16 bytes and the byte before them: in flight while the read starts are marked
     const uint64_t q0 = seg + 16 * (uint64_t)t;
-    uint32_t c[16];
+    uint4 v = make_uint4(0, 0, 0, 0);
     uint32_t prev = 0x100u;
     int nval = 0;
     if (q0 < n_bases) {
         nval = n_bases - q0 >= 16 ? 16 : (int)(n_bases - q0);
         if (q0) prev = s[q0 - 1];
-        if (nval == 16) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(s + q0);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 16; j++) c[j] = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; j++) c[j] = j < nval ? s[q0 + j] : 0u;
-        }
+        if (nval == 16) v = *reinterpret_cast<const uint4 *>(s + q0);
     }
-    const uint32_t sb = (starts[(16 * t) >> 5] >> ((16 * t) & 31)) & 0xFFFFu;
+    // starts of the non-empty reads inside the segment (read r_s itself when it starts exactly here); none in most segments of long reads
+    const uint64_t r_first = r_s + (a_s == seg ? 0 : 1);
+    const bool any_starts = r_first <= r_e; // block-uniform
+    if (any_starts) {
+        if (t < (int)(HS_SEG / 32)) starts[t] = 0;
+        __syncthreads();
+        for (uint64_t r = r_first + (uint64_t)t; r <= r_e; r += HS_THREADS) {
+            const uint64_t a = read_off[r];
+            if (a >= seg && a < seg_end && read_off[r + 1] > a) atomicOr(&starts[(a - seg) >> 5], 1u << ((a - seg) & 31));
+        }
+        __syncthreads();
+    }
+    uint32_t c[16];
+    if (nval == 16) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++) c[j] = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) c[j] = j < nval ? s[q0 + j] : 0u;
+    }
+    const uint32_t sb = any_starts ? (starts[(16 * t) >> 5] >> ((16 * t) & 31)) & 0xFFFFu : 0u;
     uint32_t heads = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -135,11 +134,10 @@ __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
     emax = emax > wmax ? emax : wmax;
     // compact into LDS first, then write whole lines: the outputs of a segment are one contiguous range.  The bytes are staged
     // at the alignment they will have in o_hpc (g mod 4), so that the copy below moves aligned dwords on both sides.
-    const uint64_t g = sh_g;
     const uint32_t mis = (uint32_t)(((uintptr_t)o_hpc + g) & 3u);
     uint32_t slot = esum; // segment-relative
     const uint32_t carry = emax;
-    uint64_t cur = carry ? seg + carry - 1 : sh_start; // start of the read the current byte belongs to
+    uint64_t cur = carry ? seg + carry - 1 : a_s; // start of the read the current byte belongs to
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         if ((sb >> j) & 1) cur = q0 + j;
@@ -172,16 +170,20 @@ __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
 
 } // namespace
 
-size_t hpc_segment_index_words(uint64_t n_bases) { return (size_t)((n_bases + HS_SEG - 1) / HS_SEG) + 1; }
+// workspace of the per-segment index, in 32-bit words: seg_g and seg_a (64-bit each), then seg_read0 with one entry past the end
+size_t hpc_segment_index_words(uint64_t n_bases) { return 5 * (size_t)((n_bases + HS_SEG - 1) / HS_SEG) + 8; }
 
 hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
-                               const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint32_t *seg_read0 /* hpc_segment_index_words */,
+                               const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint32_t *seg_index /* hpc_segment_index_words, 8-byte aligned */,
                                uint8_t *o_hpc, uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle) {
     if (n_reads == 0 || n_bases == 0) return hipSuccess;
     const uint64_t segs = (n_bases + HS_SEG - 1) / HS_SEG;
-    hipLaunchKernelGGL(hpc_segment_index_kernel, dim3((unsigned)((segs + 255) / 256)), dim3(256), 0, st, read_off, n_reads, segs, seg_read0);
-    hipLaunchKernelGGL(hpc_segment_kernel, dim3((unsigned)segs), dim3(HS_THREADS), 0, st, bases, read_off, n_reads, n_bases,
-                       hpc_off, blk_off, read_c0, seg_read0, o_hpc, o_pos, capacity, rle);
+    uint64_t *seg_g = reinterpret_cast<uint64_t *>(seg_index), *seg_a = seg_g + segs;
+    uint32_t *seg_read0 = reinterpret_cast<uint32_t *>(seg_a + segs);
+    hipLaunchKernelGGL(hpc_segment_index_kernel, dim3((unsigned)((segs + 1 + 255) / 256)), dim3(256), 0, st, bases, read_off, n_reads, segs, hpc_off, blk_off,
+                       read_c0, seg_g, seg_a, seg_read0, rle);
+    hipLaunchKernelGGL(hpc_segment_kernel, dim3((unsigned)segs), dim3(HS_THREADS), 0, st, bases, read_off, n_reads, n_bases, seg_g, seg_a, seg_read0, o_hpc,
+                       o_pos, capacity, rle);
     return hipGetLastError();
 }
 

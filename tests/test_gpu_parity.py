@@ -468,6 +468,34 @@ def test_standalone_hpc_batches(eng, oracle):
             eng.hpc_device(d_b.data_ptr() + shift, d_o.data_ptr(), len(reads), len(bases), d_ho.data_ptr(), d_h.data_ptr(), d_p.data_ptr(), n // 2)
         assert e.value.status == 7
         assert d_h[:n // 2].cpu().numpy().tobytes() == exp_s[:n // 2] and int(d_h[n // 2:].max().item()) == 0
+        # output arrays that start at any byte / word: the compressed bytes leave the kernel as aligned dwords with a byte head and tail
+        for o_shift in (1, 2, 3):
+            d_h2 = torch.zeros(len(bases) + 8, dtype=torch.uint8, device=dev)
+            d_p2 = torch.zeros(len(bases) + 8, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            assert eng.hpc_device(d_b.data_ptr() + shift, d_o.data_ptr(), len(reads), len(bases), d_ho.data_ptr(), d_h2.data_ptr() + o_shift,
+                                  d_p2.data_ptr() + 4 * o_shift, len(bases)) == n
+            assert d_h2[o_shift:o_shift + n].cpu().numpy().tobytes() == exp_s and int(d_h2[:o_shift].max().item()) == 0
+            assert int(d_h2[o_shift + n:].max().item()) == 0
+            assert (d_p2[o_shift:o_shift + n].cpu().numpy().view(np.uint32) == exp_p).all()
+    # hundreds of reads inside one 4096-byte segment (more read starts than the block has threads), empty ones among them
+    lens = [int(x) for x in rng.integers(0, 9, size=6000)] + [5000] + [int(x) for x in rng.integers(0, 4, size=3000)]
+    reads = [rand_read(rng, n, hp=0.5) for n in lens]
+    bases, off = pkg.pack_reads(reads)
+    exp = [oracle.hpc(r, 2) if len(r) else (b"", np.zeros(0, dtype=np.uint64)) for r in reads]
+    exp_s = b"".join(e[0] for e in exp)
+    exp_p = np.concatenate([np.asarray(e[1], dtype=np.uint32) for e in exp])
+    exp_off = np.concatenate([[0], np.cumsum([len(e[0]) for e in exp])])
+    d_b = torch.zeros(len(bases) + 32, dtype=torch.uint8, device=dev)
+    d_b[:len(bases)] = torch.from_numpy(bases).to(dev)
+    d_o = torch.from_numpy(off.astype(np.int64)).to(dev)
+    d_ho = torch.zeros(len(reads) + 1, dtype=torch.int64, device=dev)
+    d_h = torch.zeros(len(bases) + 1, dtype=torch.uint8, device=dev)
+    d_p = torch.zeros(len(bases) + 1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    n = eng.hpc_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), len(bases), d_ho.data_ptr(), d_h.data_ptr(), d_p.data_ptr(), len(bases))
+    assert n == len(exp_s) and (d_ho.cpu().numpy() == exp_off).all()
+    assert d_h[:n].cpu().numpy().tobytes() == exp_s and (d_p[:n].cpu().numpy().view(np.uint32) == exp_p).all()
 
 
 def test_encode_rle_flavour(eng, oracle, ecoli):
