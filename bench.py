@@ -183,7 +183,10 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+            # RCCL over xGMI for tensors in HBM, gloo for tensors in host memory: the extraction itself has no collective (reads are
+            # sharded), so if RCCL cannot come up on a node the few control words (the barrier, the max over ranks of the time, the
+            # count sums) travel over gloo instead and the line says so -- a broken fabric must not cost the measurement
+            dist.init_process_group("cpu:gloo,cuda:nccl")
         else:
             dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
@@ -193,10 +196,28 @@ def main():
     if dist is not None:
         # proof that the process group really spans N ranks on N devices: every rank contributes (rank, device index, PCI bus id)
         props = torch.cuda.get_device_properties(dev)
-        me = torch.tensor([rank, local_rank, hash(getattr(props, "pci_bus_id", local_rank)) & 0x7FFFFFFF], dtype=torch.int64, device=red_dev)
-        allv = [torch.zeros_like(me) for _ in range(dist.get_world_size())]
-        dist.all_gather(allv, me)
-        collective = {"backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "world_size_seen": dist.get_world_size(),
+        words = [rank, local_rank, hash(getattr(props, "pci_bus_id", local_rank)) & 0x7FFFFFFF]
+        rccl_error = None
+        if red_dev.type == "cuda":
+            try:
+                me = torch.tensor(words, dtype=torch.int64, device=red_dev)
+                allv = [torch.zeros_like(me) for _ in range(dist.get_world_size())]
+                dist.all_gather(allv, me)
+                torch.cuda.synchronize(dev)
+                ok = 1
+            except Exception as e:  # (e.g. two ranks mapped to one device, a fabric that is down)
+                rccl_error, ok = "%s: %s" % (type(e).__name__, str(e).strip().splitlines()[-1][:200]), 0
+            agree = torch.tensor([ok], dtype=torch.int32)  # every rank takes the same road from here
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) == 0:
+                red_dev = torch.device("cpu")
+                rccl_error = rccl_error or "RCCL failed on another rank"
+        if red_dev.type == "cpu":
+            me = torch.tensor(words, dtype=torch.int64)
+            allv = [torch.zeros_like(me) for _ in range(dist.get_world_size())]
+            dist.all_gather(allv, me)
+        backend_text = args.backend if args.backend != "nccl" else ("nccl (RCCL)" if rccl_error is None else "gloo (RCCL unusable: %s)" % rccl_error)
+        collective = {"backend": backend_text, "world_size_seen": dist.get_world_size(),
                       "ranks": [int(v[0]) for v in allv], "devices": [int(v[1]) for v in allv],
                       "distinct_devices": len({(int(v[1]), int(v[2])) for v in allv}), "visible_devices": n_dev,
                       "device_name": props.name}
@@ -278,7 +299,11 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            torch.cuda.synchronize(dev)
+            if red_dev.type == "cuda":
+                dist.barrier(device_ids=[dev.index])
+            else:  # (gloo: an all-reduce of one word in host memory is the barrier)
+                dist.all_reduce(torch.zeros(1, dtype=torch.int32))
         torch.cuda.synchronize(dev)
 
     def timed(m, steps, warmup, strict=True):
@@ -494,7 +519,7 @@ def main():
     if args.count == "on" or (args.count == "auto" and world > 1):
         ops = sharding.EngineCountOps(eng, dev)
         keys = outs["hash"][: counts["n_kminmers"]]
-        sharding.count_kminmers(keys, ops, dist, collectives_on_device=(args.backend == "nccl"))  # warm-up (table allocation)
+        sharding.count_kminmers(keys, ops, dist, collectives_on_device=(red_dev.type == "cuda"))  # warm-up (table allocation)
         # three passes, each timed on its own (max over ranks); the median is reported: in a process that has initialised RCCL
         # one call in a few takes ~0.7 s instead of 45 ms whatever it does (tools/debug/count_under_nccl.py) -- a background
         # thread of the process group, not this path
@@ -502,7 +527,7 @@ def main():
         for _ in range(3):
             barrier()
             tc0 = time.perf_counter()
-            cr = sharding.count_kminmers(keys, ops, dist, collectives_on_device=(args.backend == "nccl"))
+            cr = sharding.count_kminmers(keys, ops, dist, collectives_on_device=(red_dev.type == "cuda"))
             barrier()
             tc = time.perf_counter() - tc0
             if dist is not None:
@@ -515,7 +540,7 @@ def main():
         # plus one 12-byte table slot touched per insert and the 12-byte slots swept by the compaction (>= 2 slots per key)
         count_line = {"n_keys": cr["n_keys"], "n_distinct": cr["n_distinct"], "ms": round(tc * 1e3, 3), "ms_passes": [round(x * 1e3, 3) for x in tcs],
                       "keys_per_s": round(cr["n_keys"] / tc / 1e9, 3), "unit": "G keys/s",
-                      "exchange": None if world == 1 else "all_to_all_single by hash prefix (%s), 8 B per key" % args.backend}
+                      "exchange": None if world == 1 else "all_to_all_single by hash prefix (%s), 8 B per key" % (collective or {}).get("backend", args.backend)}
 
     # ---- roofline (rank 0's launch): SURVEY.md 8d  B = N_bases*1 + N_kminmers*17 + 16*(N_reads+1) --------------------
     # each input byte once, each k-min-mer once (u64 hash + u32 start + u32 end + u8 rev), both offset tables;
@@ -668,8 +693,11 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        barrier()
+        try:
+            dist.destroy_process_group()
+        except Exception:  # (a communicator that never came up: nothing to tear down)
+            pass
     eng.close()
 
 

@@ -78,6 +78,19 @@ def test_strong_scaling_cuts_one_fixed_batch(tmp_path):
     assert one["counts"]["kminmers"] == two["counts"]["kminmers"]
 
 
+@pytest.mark.gpu
+def test_rccl_that_cannot_come_up_does_not_cost_the_line(tmp_path):
+    """default backend (RCCL for tensors in HBM, gloo for host memory) with two ranks on ONE device: RCCL refuses ("Duplicate GPU"),
+    every rank agrees to move the control words (barrier, max of the times, count sums) to gloo, and the line says which it was --
+    the extraction itself has no collective"""
+    tmp = str(tmp_path)
+    one = run_bench(["--gpus", "1", "--reads", "4000"], tmp, "f1")
+    two = run_bench(["--gpus", "2", "--reads", "2000", "--single-device"], tmp, "f2")
+    assert two["collective"]["backend"].startswith("gloo (RCCL unusable") and two["collective"]["world_size_seen"] == 2
+    assert two["verified_vs_oracle"]["ok"] and {k: one["counts"][k] for k in ("bases", "kminmers")} == {k: two["counts"][k] for k in ("bases", "kminmers")}
+    assert two["downstream_count"]["n_keys"] == two["counts"]["kminmers"]
+
+
 def test_more_ranks_than_gpus_fails_loudly():
     """no GPU (or fewer than --gpus) visible: every rank says so and exits non-zero before anything touches a device"""
     import torch
