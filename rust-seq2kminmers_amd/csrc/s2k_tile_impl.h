@@ -123,9 +123,17 @@ constexpr int PROFILE_LDS_BYTES = TW * 16 * 8;
 typedef uint64_t *ph_ptr_t;
 constexpr int PROFILE_LDS_BYTES = 0;
 #endif
-constexpr int TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c], l-1)};  OUT table at 2048: {rotl(h[c], l), rotr(rc[c], 1)}
+constexpr int SEED_TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c], l-1)};  OUT table at 2048: {rotl(h[c], l), rotr(rc[c], 1)}
+#ifndef S2K_SEL8
+#define S2K_SEL8 1
+#endif
+// Hpc: behind the seed tables, sel8[m][n] = index of the n-th set bit of the byte m (2 KiB): the last three levels of the back-map's
+// select-nth-set-bit are one look-up
+constexpr int TABLE_BYTES = SEED_TABLE_BYTES; // (tools/experiments)
+constexpr int SEL8_OFF = SEED_TABLE_BYTES, SEL8_BYTES = S2K_SEL8 ? 256 * 8 : 0;
+template <bool HPC> constexpr int table_bytes() { return SEED_TABLE_BYTES + (HPC ? SEL8_BYTES : 0); }
 template <bool HPC>
-constexpr int block_lds_bytes() { return TABLE_BYTES + TW * (int)sizeof(WaveLdsT<HPC>) + PROFILE_LDS_BYTES; }
+constexpr int block_lds_bytes() { return table_bytes<HPC>() + TW * (int)sizeof(WaveLdsT<HPC>) + PROFILE_LDS_BYTES; }
 // one block of TW = 12 waves per CU: it may use the whole 160 KiB (MI355X_MICROARCH.md: "a single workgroup may declare all 160 KiB")
 #ifndef S2K_EXPERIMENT
 static_assert(block_lds_bytes<true>() <= 160 * 1024, "the block of a CU must fit its 160 KiB of LDS");
@@ -165,6 +173,14 @@ __device__ inline uint32_t select_nth_32(uint32_t w, uint32_t n) {
     c = __popc(w & 0x3u);    if (n >= c) { n -= c; r += 2;  w >>= 2; }
     c = w & 1u;              if (n >= c) { r += 1; }
     return r;
+}
+// the same with the table sel8 (LDS, see SEL8_OFF) for the last eight bits
+__device__ __forceinline__ uint32_t select_nth_32_lut(uint32_t w, uint32_t n) {
+    typedef __attribute__((address_space(3))) const uint8_t *lds_cu8;
+    uint32_t r = 0, c;
+    c = __popc(w & 0xFFFFu); if (n >= c) { n -= c; r += 16; w >>= 16; }
+    c = __popc(w & 0xFFu);   if (n >= c) { n -= c; r += 8;  w >>= 8; }
+    return r + reinterpret_cast<lds_cu8>((uint32_t)SEL8_OFF)[8u * (w & 0xFFu) + n];
 }
 // Seed look-ups of the hot loop.  The two 2 KiB tables sit at LDS byte offsets 0 (IN pairs) and 2048 (OUT
 // pairs); the kernel has no static LDS, so the dynamic region starts at 0 (checked at kernel entry).  The byte
@@ -688,7 +704,7 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
                 word = w[d + 1];
             }
         }
-        return 32 * g + select_nth_32(word, n);
+        return 32 * g + (S2K_SEL8 ? select_nth_32_lut(word, n) : select_nth_32(word, n));
     };
     const uint32_t lo1 = owner(x);
     const uint32_t ln = lo1 < 63 ? lo1 + 1 : 63u; // the raw lane after it
@@ -1320,11 +1336,16 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         tab[c] = make_uint2(h, rotl32(r, l - 1));
         tab[256 + c] = make_uint2(rotl32(h, l), rotr32(r, 1));
     }
+    if constexpr (HPC && S2K_SEL8 != 0)
+        for (int c = threadIdx.x; c < 256 * 8; c += 64 * TW) {
+            const uint32_t m = (uint32_t)c >> 3, n = (uint32_t)c & 7u;
+            smem[SEL8_OFF + c] = (uint8_t)(n < (uint32_t)__popc(m) ? select_nth_32(m, n) : 0u);
+        }
     __syncthreads(); // the only workgroup barrier; waves are independent from here on
 #ifdef S2K_DEBUG_KNOBS
     const uint64_t dbg_mt0 = __builtin_amdgcn_s_memtime(), dbg_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    WL &S = *reinterpret_cast<WL *>(smem + TABLE_BYTES + (size_t)w * sizeof(WL));
+    WL &S = *reinterpret_cast<WL *>(smem + table_bytes<HPC>() + (size_t)w * sizeof(WL));
     uint8_t *D = S.buf + HS_OFF;
     const uint64_t n_waves = (uint64_t)gridDim.x * TW;
     uint64_t t = tile_begin + (uint64_t)blockIdx.x * TW + w;
@@ -1332,7 +1353,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     if (__builtin_amdgcn_readfirstlane((int)counts->bad_input)) return; // malformed read table (validate_read_off_kernel): touch nothing
     uint64_t stamp = __builtin_amdgcn_s_memtime();
 #ifdef S2K_PROFILE
-    ph_ptr_t ph = reinterpret_cast<ph_ptr_t>((uint32_t)(TABLE_BYTES + TW * sizeof(WL) + (size_t)w * 128)); // (the dynamic region starts at LDS address 0)
+    ph_ptr_t ph = reinterpret_cast<ph_ptr_t>((uint32_t)(table_bytes<HPC>() + TW * sizeof(WL) + (size_t)w * 128)); // (the dynamic region starts at LDS address 0)
     if (lane0 < 16) ph[lane0] = 0;
     wave_sync();
 #else
