@@ -956,6 +956,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                 todo &= todo - 1;
                 const int32_t hbz = (int32_t)bcast((uint32_t)HB, z);
                 const int wz = (int)wclr + (int)bcast(wextra, z);
+                if (hbz - wz >= (int)nh) continue; // (wave-uniform: the next read starts so far behind the tile that the range holds none of its positions -- most tiles)
                 const int lo = hbz - wz - (int)(Tq * lane), hi = hbz - 1 - (int)(Tq * lane); // lane-local, inclusive
                 if (hi >= 0 && lo < (int)Tq) {
 #pragma unroll
