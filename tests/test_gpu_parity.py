@@ -1242,3 +1242,14 @@ def test_contexts_are_independent_across_threads(oracle):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_fuzz_standalone_hpc_short():
+    """tools/fuzz_hpc.py (random ragged batches through s2k_hpc_device / _ex against the oracle's hpc / encode_rle: both rules, aligned and
+    unaligned base pointers, output arrays at odd offsets, thousands of reads in one segment, runs longer than a segment), 200 batches"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_hpc.py"), "77", "200"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "0 mismatches" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
