@@ -667,6 +667,12 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     return R;
 }
 
+// bits [0, v) of a word: none for v <= 0, all for v >= 32 (v_med3_i32, v_bfm_b32, compare, select)
+__device__ __forceinline__ uint32_t bits_below(int v) {
+    const int t = v < 0 ? 0 : (v > 32 ? 32 : v);
+    const uint32_t m = (1u << ((uint32_t)t & 31u)) - 1u;
+    return t == 32 ? 0xFFFFFFFFu : m;
+}
 // x / Tq for a hash position x < 64 Tq, Tq = 16 np, np in {1, 3, 5, 7, 9}: (x >> 4) / np by a 16-bit reciprocal (rcp = 65536 / np + 1:
 // exact while (x >> 4) (rcp np - 65536) < 65536, i.e. for all x < 2^16).  One 24-bit multiply and two shifts instead of the 64-bit
 // multiply-add pair the compiler made of __umulhi with a scalar operand.
@@ -825,15 +831,13 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     //     same read, src/nthash_hpc.rs:265-267).  The first read start at or after the tile end (or the
     //     end of the stream) is the one external boundary.
     const uint32_t wclr = HPC ? (sem.keep_last ? l - 1 : l) : l - 1; // Hpc drops the last l-mer of a read (src/nthash_hpc.rs:265-267)
-    const uint32_t rcpTq = 65536u / (Tq >> 4) + 1u; // see div_tq
+    const uint32_t rcpTq = Tq == 112u ? 9363u : Tq == 48u ? 21846u : Tq == 80u ? 13108u : Tq == 144u ? 7282u : 65537u; // 65536 / (Tq / 16) + 1 for Tq / 16 in {7, 3, 5, 9, 1}: see div_tq (a division costs ~25 instructions per tile)
     uint32_t vm[5]; // validated hit mask of this lane
     {
         int vc = (int)nh - (int)(Tq * lane); // hash positions of this lane that exist
 #pragma unroll
         for (int d = 0; d < 5; d++) {
-            int v = vc - 32 * d;
-            uint32_t keep = v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
-            vm[d] = raw[d] & keep;
+            vm[d] = raw[d] & bits_below(vc - 32 * d);
         }
     }
     const uint64_t tile_end = t0 + tile_len;
@@ -1043,9 +1047,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                 uint32_t c = 0;
 #pragma unroll
                 for (int d = 0; d < 5; d++) {
-                    const int v = lim - 32 * d;
-                    const uint32_t keep = v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
-                    c += __popc(vm[d] & keep);
+                    c += __popc(vm[d] & bits_below(lim - 32 * d));
                 }
                 // lanes left of the boundary's lane count everything, lanes right of it nothing: the total is the
                 // exclusive offset of that lane plus its own share -- one v_readlane instead of a wave scan
