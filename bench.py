@@ -179,6 +179,8 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: gloo need not resolve the host name (it may not resolve in a container)
         if args.single_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
