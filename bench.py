@@ -302,10 +302,9 @@ def main():
     def barrier():
         if dist is not None:
             torch.cuda.synchronize(dev)
-            if red_dev.type == "cuda":
-                dist.barrier(device_ids=[dev.index])
-            else:  # (gloo: an all-reduce of one word in host memory is the barrier)
-                dist.all_reduce(torch.zeros(1, dtype=torch.int32))
+            # the barrier: an all-reduce of one word where the collective words live (HBM over RCCL, or host memory over gloo); nobody leaves
+            # it before everybody has entered it
+            dist.all_reduce(torch.zeros(1, dtype=torch.int32, device=red_dev))
         torch.cuda.synchronize(dev)
 
     def timed(m, steps, warmup, strict=True):
