@@ -136,6 +136,10 @@ struct DevBuf {
     }
 };
 
+constexpr uint32_t MAX_DESC_CHUNKS = 64;
+constexpr size_t CTRL_XOR_OFF = (sizeof(Counts) + 255) & ~(size_t)255;
+constexpr size_t CTRL_CURSORS_OFF = CTRL_XOR_OFF + XOR_SHARDS * sizeof(uint64_t);
+
 struct Arena {
     char *base;
     size_t off, cap;
@@ -180,9 +184,12 @@ struct s2k_ctx {
     bool force_full_runs = false;                 // S2K_FULL_RUNS=1 (A/B, tests): HpcSimd counts the runs of every read in a pre-pass instead of looking back from tile to tile
     bool trace = false;                           // S2K_TRACE: one line on stderr whenever a call is run again (record pool too small, a fall-back to another path)
     uint64_t host_batch = 1ull << 29;             // bases per sub-batch of s2k_extract (s2k_set_host_batch)
+    // counters, XOR shards and the tile cursors of up to MAX_DESC_CHUNKS launches are ONE allocation (d_counts is its start): one memset
+    // per call instead of three (every launch in front of the first minimizer kernel is ~7 us of an otherwise idle device)
     Counts *d_counts = nullptr;
     Counts *h_counts = nullptr; // pinned
     uint64_t *d_xor = nullptr;
+    uint64_t *d_cursors = nullptr;
     std::vector<hipEvent_t> evs; // 6 events per timed call, in call order since timing was enabled
     size_t ev_used = 0;           // sets handed out
     hipEvent_t *ev = nullptr;     // set of the current / last call
@@ -323,7 +330,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
     // ---- carve the workspace (first pass sizes, second pass pointers) --------------------------
     Arena a{nullptr, 0, 0};
     uint32_t *mn_cnt = nullptr, *tile_read0 = nullptr, *tile_cnt = nullptr;
-    uint64_t *mn_off = nullptr, *tile_rec_off = nullptr, *tile_goff = nullptr, *scan_tmp = nullptr, *pool_cursor = nullptr;
+    uint64_t *mn_off = nullptr, *tile_rec_off = nullptr, *tile_goff = nullptr, *scan_tmp = nullptr, *pool_cursor = ctx->d_cursors;
     const bool want_runs = !c.serial && c.sem.hpc && c.sem.tail_quirk; // HpcSimd on the tiled kernel
     // descriptor path (default): 8-byte tile-relative records + one word and a segment list per tile, a scan over the tile words,
     // and a k-min-mer kernel that needs no per-read table (s2k_desc.hip).  Legacy path: 16-byte records with the read index,
@@ -339,6 +346,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
         const uint64_t min_chunk = ctx->desc_chunks ? 64 : 12 * 3072; // tiles: a dozen per resident wave (a forced count -- tests -- only needs 64)
         if ((uint64_t)n_chunks * min_chunk > n_tiles) n_chunks = (uint32_t)(n_tiles / min_chunk);
         if (n_chunks < 1) n_chunks = 1;
+        if (n_chunks > MAX_DESC_CHUNKS) n_chunks = MAX_DESC_CHUNKS; // (the cursors of the launches live in the context's control block)
     }
     unsigned long long *d_agg = nullptr, *d_scan = nullptr;
     TileMeta *d_meta = nullptr;
@@ -352,7 +360,6 @@ s2k_status enqueue(s2k_ctx *ctx) {
         mn_cnt = a.take<uint32_t>(n_reads + 1);
         mn_off = o.mn_off ? o.mn_off : a.take<uint64_t>(n_reads + 1);
         scan_tmp = a.take<uint64_t>(scan_tmp_bytes(n_reads > n_tiles ? n_reads : n_tiles) / sizeof(uint64_t) + 1);
-        pool_cursor = a.take<uint64_t>((size_t)CURSOR_WORDS * (use_desc ? n_chunks : 1));
         if (!c.serial) {
             tile_read0 = a.take<uint32_t>(n_tiles + 1);
             tile_cnt = a.take<uint32_t>(n_tiles + 1);
@@ -407,9 +414,8 @@ s2k_status enqueue(s2k_ctx *ctx) {
         ctx->ev_used++;
         S2K_TRY(hipEventRecord(ctx->ev[0], st), "event");
     }
-    S2K_TRY(hipMemsetAsync(ctx->d_counts, 0, sizeof(Counts), st), "memset counts");
-    S2K_TRY(hipMemsetAsync(ctx->d_xor, 0, XOR_SHARDS * sizeof(uint64_t), st), "memset xor");
-    S2K_TRY(hipMemsetAsync(pool_cursor, 0, (size_t)CURSOR_WORDS * (use_desc ? n_chunks : 1) * sizeof(uint64_t), st), "memset cursors");
+    S2K_TRY(hipMemsetAsync(ctx->d_counts, 0, CTRL_CURSORS_OFF + (size_t)CURSOR_WORDS * (use_desc ? n_chunks : 1) * sizeof(uint64_t), st),
+            "memset counters, xor shards, cursors");
     // the read table is caller memory in HBM: checked on the device, first thing in the stream; the kernels below look at
     // the verdict (or clamp what they read from the table) and the host reports it in finish()
     S2K_TRY(launch_validate_read_off(c.d_read_off, n_reads, n_bases, &ctx->d_counts->bad_input, st), "read table validation");
@@ -421,8 +427,14 @@ s2k_status enqueue(s2k_ctx *ctx) {
         S2K_TRY(launch_serial_write(c.d_bases, c.d_read_off, n_reads, n_bases, c.sem, mn_off, rec, ctx->d_counts, st), "serial write kernel");
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
     } else {
-        S2K_TRY(hipMemsetAsync(mn_cnt, 0, (n_reads + 1) * sizeof(uint32_t), st), "memset mn_cnt");
-        S2K_TRY(launch_tile_index(c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, st), "tile index kernel");
+        if (!use_desc) S2K_TRY(hipMemsetAsync(mn_cnt, 0, (n_reads + 1) * sizeof(uint32_t), st), "memset mn_cnt"); // (per-read counts: legacy path only)
+        // Descriptor path: every tile writes its word (dense_phase<DESC>); the array still starts as the IDENTITY of the scan -- dep and pass
+        // set: "no minimizers, p handed on" (agg_identity, s2k_dev.h) -- so that a tile which left none would drop nothing.  (Zero is NOT the
+        // identity: it unpacks to dep = pass = false, q = 0, i.e. "a read ends here", and would cut every window spanning the tile.)  The
+        // tile index kernel writes it on its way: one thread per tile there too.
+        S2K_TRY(launch_tile_index(c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, use_desc ? (unsigned long long *)d_agg : nullptr,
+                                  agg_pack(0, 0, 0, 0, true, true), st),
+                "tile index kernel");
         Sem sem = c.sem;
         sem.read_runs = nullptr;
         // HpcSimd: the tail rule needs the run count of the whole read.  Default: the tiles tell each other (Sem::tile_heads, a
@@ -457,10 +469,6 @@ s2k_status enqueue(s2k_ctx *ctx) {
             dz.o_mn_jend = o.mn_jend;
             dz.o_mn_hash = o.mn_hash;
             dz.xor_shards = (unsigned long long *)ctx->d_xor;
-            // Every tile writes its word (dense_phase<DESC>); the array still starts as the IDENTITY of the scan -- dep and pass set:
-            // "no minimizers, p handed on" (agg_identity, s2k_dev.h) -- so that a tile which left none would drop nothing.  (Zero is NOT
-            // the identity: it unpacks to dep = pass = false, q = 0, i.e. "a read ends here", and would cut every window spanning the tile.)
-            S2K_TRY(launch_fill_u64((unsigned long long *)d_agg, n_tiles, agg_pack(0, 0, 0, 0, true, true), st), "tile words fill");
             if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
             if (n_chunks == 1) {
                 S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, nullptr,
@@ -692,8 +700,11 @@ s2k_ctx *s2k_create(int device, s2k_status *status) {
     ctx->device = device;
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     ctx->own_stream = ok;
-    ok = ok && hipMalloc((void **)&ctx->d_counts, sizeof(Counts)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&ctx->d_xor, XOR_SHARDS * sizeof(uint64_t)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_counts, CTRL_CURSORS_OFF + (size_t)CURSOR_WORDS * MAX_DESC_CHUNKS * sizeof(uint64_t)) == hipSuccess;
+    if (ok) {
+        ctx->d_xor = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(ctx->d_counts) + CTRL_XOR_OFF);
+        ctx->d_cursors = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(ctx->d_counts) + CTRL_CURSORS_OFF);
+    }
     ok = ok && hipHostMalloc((void **)&ctx->h_counts, sizeof(Counts), hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         *status = S2K_ERR_DEVICE;
@@ -726,8 +737,7 @@ void s2k_destroy(s2k_ctx *ctx) {
     for (hipEvent_t e : ctx->chunk_ev) (void)hipEventDestroy(e);
     if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
     if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
-    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
-    if (ctx->d_xor) (void)hipFree(ctx->d_xor);
+    if (ctx->d_counts) (void)hipFree(ctx->d_counts); // (d_xor and d_cursors lie inside it)
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     for (hipEvent_t e : ctx->evs) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -272,7 +272,7 @@ hipError_t launch_finalize(Counts *counts, const uint64_t *xor_shards, const uin
                            uint64_t km_capacity, uint64_t mn_capacity, hipStream_t st);
 
 hipError_t launch_tile_index(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles,
-                             uint32_t *tile_read0, hipStream_t st);
+                             uint32_t *tile_read0, unsigned long long *tile_words /* or nullptr */, unsigned long long word0, hipStream_t st);
 // desc != nullptr: descriptor path (8-byte records in rec.hash / rec.j, agg word + meta per tile; tile_rec_off / tile_cnt / mn_cnt unused).
 // The launch works on the tiles [tile_begin, n_tiles); pool_cursor must be zeroed (CURSOR_WORDS words) for every launch.
 hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
