@@ -418,9 +418,8 @@ s2k_status enqueue(s2k_ctx *ctx) {
             "memset counters, xor shards, cursors");
     // the read table is caller memory in HBM: checked on the device, first thing in the stream; the kernels below look at
     // the verdict (or clamp what they read from the table) and the host reports it in finish()
-    S2K_TRY(launch_validate_read_off(c.d_read_off, n_reads, n_bases, &ctx->d_counts->bad_input, st), "read table validation");
-
     if (c.serial) {
+        S2K_TRY(launch_validate_read_off(c.d_read_off, n_reads, n_bases, &ctx->d_counts->bad_input, st), "read table validation");
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[1], st), "event");
         S2K_TRY(launch_serial_count(c.d_bases, c.d_read_off, n_reads, n_bases, c.sem, mn_cnt, st), "serial count kernel");
         S2K_TRY(launch_scan_u32(mn_cnt, n_reads, mn_off, scan_tmp, 0, st), "scan");
@@ -431,10 +430,10 @@ s2k_status enqueue(s2k_ctx *ctx) {
         // Descriptor path: every tile writes its word (dense_phase<DESC>); the array still starts as the IDENTITY of the scan -- dep and pass
         // set: "no minimizers, p handed on" (agg_identity, s2k_dev.h) -- so that a tile which left none would drop nothing.  (Zero is NOT the
         // identity: it unpacks to dep = pass = false, q = 0, i.e. "a read ends here", and would cut every window spanning the tile.)  The
-        // tile index kernel writes it on its way: one thread per tile there too.
-        S2K_TRY(launch_tile_index(c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, use_desc ? (unsigned long long *)d_agg : nullptr,
-                                  agg_pack(0, 0, 0, 0, true, true), st),
-                "tile index kernel");
+        // read-table kernel writes it on its way: validation, tile index and this fill are one launch.
+        S2K_TRY(launch_read_table(c.d_read_off, n_reads, n_bases, n_tiles, &ctx->d_counts->bad_input, tile_read0,
+                                  use_desc ? (unsigned long long *)d_agg : nullptr, agg_pack(0, 0, 0, 0, true, true), st),
+                "read table kernel");
         Sem sem = c.sem;
         sem.read_runs = nullptr;
         // HpcSimd: the tail rule needs the run count of the whole read.  Default: the tiles tell each other (Sem::tile_heads, a

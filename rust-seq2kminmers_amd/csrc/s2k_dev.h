@@ -251,6 +251,10 @@ size_t hpc_segment_index_words(uint64_t n_bases); // uint32 words of seg_index (
 // read_off[0] == 0, non-decreasing, read_off[n_reads] == n_bases, no read longer than 2^32 - 2: anything else sets BAD_*
 // bits in *bad (a device word); the kernels that follow in the stream look at it and do nothing when it is set
 hipError_t launch_validate_read_off(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint32_t *bad, hipStream_t st);
+// the same checks + tile_read0[0 .. n_tiles] (the read that holds the first base of every tile; entry n_tiles: n_reads - 1) + (tile_words != nullptr)
+// tile_words[0 .. n_tiles) = word0, in one pass over the read table (s2k_util.hip: read_table_kernel)
+hipError_t launch_read_table(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles, uint32_t *bad, uint32_t *tile_read0,
+                             unsigned long long *tile_words, unsigned long long word0, hipStream_t st);
 
 hipError_t launch_synth(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d, hipStream_t st);
 hipError_t launch_fill_u64(unsigned long long *d, uint64_t n, unsigned long long v, hipStream_t st);
@@ -271,8 +275,6 @@ hipError_t launch_kminmers(uint64_t n_tiles, const uint64_t *tile_rec_off, const
 hipError_t launch_finalize(Counts *counts, const uint64_t *xor_shards, const uint64_t *mn_total, const uint64_t *km_total,
                            uint64_t km_capacity, uint64_t mn_capacity, hipStream_t st);
 
-hipError_t launch_tile_index(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles,
-                             uint32_t *tile_read0, unsigned long long *tile_words /* or nullptr */, unsigned long long word0, hipStream_t st);
 // desc != nullptr: descriptor path (8-byte records in rec.hash / rec.j, agg word + meta per tile; tile_rec_off / tile_cnt / mn_cnt unused).
 // The launch works on the tiles [tile_begin, n_tiles); pool_cursor must be zeroed (CURSOR_WORDS words) for every launch.
 hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,

@@ -1,4 +1,4 @@
-// s2k_tile.hip -- host side of the tiled minimizer kernel: tile index, dispatch on l.  The kernel itself is in
+// s2k_tile.hip -- host side of the tiled minimizer kernel: dispatch on l.  The kernel itself is in
 // s2k_tile_impl.h; this unit carries its run-time-l instantiation, s2k_tile_inst.hip the compile-time ones.
 #include "s2k_tile_impl.h"
 
@@ -12,15 +12,6 @@ namespace s2k {
 S2K_STATIC_LS(S2K_DECL)
 #undef S2K_DECL
 
-
-hipError_t launch_tile_index(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles,
-                             uint32_t *tile_read0, unsigned long long *tile_words, unsigned long long word0, hipStream_t st) {
-    if (n_reads == 0) return hipSuccess;
-    uint64_t n = n_tiles + 1;
-    hipLaunchKernelGGL(tile_index_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, read_off, n_reads, n_bases,
-                       n_tiles, tile_read0, tile_words, word0);
-    return hipGetLastError();
-}
 
 hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                   uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec,

@@ -1669,26 +1669,6 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
 #endif
 }
 
-// tile_read0[t] = last read index r (0 <= r < n_reads) with read_off[r] <= min(t*TILE, n_bases); descriptor path: the tile's word starts as word0
-__global__ __launch_bounds__(256) void tile_index_kernel(const uint64_t *__restrict__ read_off, uint64_t n_reads,
-                                                         uint64_t n_bases, uint64_t n_tiles,
-                                                         uint32_t *__restrict__ tile_read0, unsigned long long *__restrict__ tile_words,
-                                                         unsigned long long word0) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > n_tiles) return;
-    if (tile_words && t < n_tiles) tile_words[t] = word0;
-    // (a malformed table only makes this search return some index in [0, n_reads); the kernels that follow do nothing then)
-    uint64_t pos = t * (uint64_t)TILE_BASES;
-    if (pos > n_bases) pos = n_bases;
-    uint64_t lo = 0, hi = n_reads - 1;
-    while (lo < hi) {
-        uint64_t mid = lo + (hi - lo + 1) / 2;
-        if (read_off[mid] <= pos) lo = mid;
-        else hi = mid - 1;
-    }
-    tile_read0[t] = (uint32_t)lo;
-}
-
 template <int L, bool HPC, bool DESC>
 hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                            uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,

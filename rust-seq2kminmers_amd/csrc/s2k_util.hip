@@ -385,6 +385,67 @@ hipError_t launch_validate_read_off(const uint64_t *read_off, uint64_t n_reads, 
     return hipGetLastError();
 }
 
+namespace {
+// One pass over the read table in front of the tiled kernels (one thread per read, O(1) loads each -- the kernel it replaces searched the table
+// once per TILE, twenty dependent loads per thread):
+//  * the checks of validate_read_off_kernel;
+//  * tile_read0[t] = the read that holds base t * TILE_BASES, i.e. the LAST read r with read_off[r] <= t * TILE_BASES (of reads that share an
+//    offset -- empty ones, then at most one that is not -- only the last holds a position), written by that read's own thread: a read
+//    [a, b) owns the tiles ceil(a / TILE) .. (b - 1) / TILE.  A read of more than eight tiles (contigs) is spread over the lanes of its wave.
+//    Entry n_tiles (the position n_bases) is n_reads - 1.  A malformed table leaves some entries unwritten; nothing reads them then (BAD_*).
+//  * descriptor path: every tile's word starts as word0 (the identity of the scan, see s2k_api.hip).
+__global__ __launch_bounds__(256) void read_table_kernel(const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles,
+                                                         uint32_t *__restrict__ bad, uint32_t *__restrict__ tile_read0,
+                                                         unsigned long long *__restrict__ tile_words, unsigned long long word0) {
+    uint32_t f = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_round = (n_reads + 63) & ~63ull; // whole waves take every trip of the loop: the ballots below need them
+    for (uint64_t r = gid; r < n_round; r += stride) {
+        uint64_t t0 = 0, cnt = 0;
+        if (r < n_reads) {
+            const uint64_t a = read_off[r], b = read_off[r + 1];
+            if (b < a) f |= BAD_ORDER;
+            else if (b - a > 0xFFFFFFFEull) f |= BAD_LONG;
+            if (b > a && b <= n_bases) { // (clamped: a malformed table must not become an out-of-bounds store)
+                t0 = (a + TILE_BASES - 1) / TILE_BASES;
+                const uint64_t t1 = (b - 1) / TILE_BASES; // t1 < n_tiles since b <= n_bases
+                cnt = t1 >= t0 ? t1 - t0 + 1 : 0;
+            }
+        }
+        if (cnt <= 8)
+            for (uint64_t i = 0; i < cnt; i++) tile_read0[t0 + i] = (uint32_t)r;
+        uint64_t big = __ballot(cnt > 8);
+        while (big) { // wave-uniform
+            const int z = __builtin_ctzll(big);
+            big &= big - 1;
+            const uint64_t zt0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(t0 >> 32), z) << 32) | (uint32_t)__shfl((int)(uint32_t)t0, z);
+            const uint64_t zc = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(cnt >> 32), z) << 32) | (uint32_t)__shfl((int)(uint32_t)cnt, z);
+            const uint32_t zr = (uint32_t)(r - (uint64_t)lane + (uint64_t)z); // lanes of a wave hold consecutive reads
+            for (uint64_t i = lane; i < zc; i += 64) tile_read0[zt0 + i] = zr;
+        }
+    }
+    if (gid == 0) {
+        if (read_off[0] != 0) f |= BAD_FIRST;
+        if (read_off[n_reads] != n_bases) f |= BAD_END;
+        tile_read0[n_tiles] = (uint32_t)(n_reads - 1);
+    }
+    if (f) atomicOr(bad, f);
+    if (tile_words)
+        for (uint64_t t = gid; t < n_tiles; t += stride) tile_words[t] = word0;
+}
+} // namespace
+
+hipError_t launch_read_table(const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles, uint32_t *bad, uint32_t *tile_read0,
+                             unsigned long long *tile_words, unsigned long long word0, hipStream_t st) {
+    if (n_reads == 0) return launch_validate_read_off(read_off, n_reads, n_bases, bad, st); // (no tiles: only the two end checks)
+    const uint64_t work = n_reads > n_tiles ? n_reads : n_tiles;
+    uint64_t blocks = (work + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(read_table_kernel, dim3((unsigned)blocks), dim3(256), 0, st, read_off, n_reads, n_bases, n_tiles, bad, tile_read0, tile_words, word0);
+    return hipGetLastError();
+}
+
 hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                   uint32_t *blk_cnt, uint64_t *blk_off, uint64_t *scan_tmp, uint32_t *runs, uint64_t *read_c0,
                                   hipStream_t st, bool rle) {
