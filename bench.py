@@ -70,6 +70,11 @@ def parse_args():
     ap.add_argument("--legacy-path", action="store_true", help="legacy records (16 B with the read index + per-read scans) instead of the descriptor path")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the rates of BASELINE configs[3] / configs[4] and of the 'next' rows "
                                                                     "(standalone HPC, minimizer triples) that the default c2 run reports beside the headline (--no-other-mode skips them too)")
+    ap.add_argument("--contexts", type=int, choices=[1, 2], default=2,
+                    help="2 (default): the timed steps alternate between two library contexts (two caller streams, two sets of output arrays), so that the "
+                         "tail of one call -- its last k-min-mer kernel, the totals, the host's look at the counts -- runs beside the first chunk of the "
+                         "next: the double buffering of a production loop.  1: one context, every call waits for the one before it (also reported as "
+                         "'one_context' when 2 is measured; --single-device rehearsals use 1)")
     ap.add_argument("--dump-shard", default=None, help="(tests) write this rank's outputs to <path>.rank<r>.npz")
     return ap.parse_args()
 
@@ -163,6 +168,10 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let bench.py spawn them)" % (args.gpus, world))
 
+    if args.contexts == 2 and not args.single_device:
+        # two contexts = four streams of the library beside torch's own: every stream gets a hardware queue of its own (the runtime's default is
+        # four per process; two streams that share a queue serialise, and a wait in one holds up the other) -- read by the HIP runtime at start-up
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import numpy as np
     import torch
     from s2k_loader import import_package
@@ -339,6 +348,66 @@ def main():
 
     dt, counts, min_ms, km_ms, pipe_ms, rank_spread = timed(mode, args.steps, args.warmup)
     assert counts["path"] == (2 if args.legacy_path else 0), "the tiled HIP kernels (descriptor path unless --legacy-path) must be the ones measured"
+    # ---- the same K steps, alternating between two contexts: what a loop over many batches gets (double buffering) -------------
+    dt_one, two_ctx = dt, None
+    if args.contexts == 2 and not args.single_device:
+        eng1 = eng2 = outs2 = None
+        try:
+            # two fresh contexts on their own (non-blocking) streams; `eng` above runs on torch's current stream, which is the legacy default
+            # stream here -- beside it a second context was measured SLOWER than one context alone
+            eng1 = pkg.Engine(local_rank)
+            eng2 = pkg.Engine(local_rank)
+            eng1.chain_after(eng2)  # the minimizer kernels of one context's call wait for those of the other's (s2k_chain_after): the persistent
+            eng2.chain_after(eng1)  # kernels never compete, and the tail of a call runs beside the first chunk of the next
+            outs2 = {kk: torch.empty_like(v) for kk, v in outs.items()}
+            o2 = pkg.DeviceOut()
+            o2.km_capacity = cap
+            o2.km_off, o2.hash, o2.start, o2.end, o2.rev = (outs2[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+            torch.cuda.synchronize(dev)
+
+            def step_i(i):
+                e, oo = (eng1, o) if i % 2 == 0 else (eng2, o2)
+                return e.extract_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases, args.l, args.k, args.density, mode, oo, sync=False,
+                                        flags=pkg.FLAG_LEGACY_PATH if args.legacy_path else 0)
+
+            for i in range(2 * ((max(args.warmup, 2) + 1) // 2)):  # untimed: both contexts have their workspace
+                step_i(i)
+            eng1.sync()
+            eng2.sync()
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step_i(i)
+            c0 = eng1.sync()
+            c1 = eng2.sync()
+            barrier()
+            dt2c = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt2c], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2c = float(t[0].item())
+            # both contexts computed the same thing (outside the timed region)
+            nk0 = c0["n_kminmers"]
+            assert c0["path"] == c1["path"] == counts["path"] and nk0 == c1["n_kminmers"] == counts["n_kminmers"] and c0["xor_hash"] == c1["xor_hash"]
+            torch.cuda.synchronize(dev)
+            for f in ("hash", "start", "end", "rev"):
+                assert torch.equal(outs[f][:nk0], outs2[f][:nk0]), "the two contexts disagree on " + f
+            assert torch.equal(outs["km_off"], outs2["km_off"])
+            two_ctx = dt2c
+        except pkg.S2kError as e:  # (no room for a second workspace: a shard sized to fill the device)
+            two_ctx = None
+            sys.stderr.write("bench.py: second context not measured (%s); the line reports one context\n" % e)
+        finally:
+            for e2 in (eng1, eng2):
+                if e2 is not None:
+                    e2.chain_after(None)
+            for e2 in (eng1, eng2):
+                if e2 is not None:
+                    e2.close()
+            del outs2
+            torch.cuda.empty_cache()
+        if two_ctx is not None:
+            dt = two_ctx
     # ---- verification outside the timed region: a read sample against the oracle ------------------
     verified = None
     if rank == 0 and args.verify_reads > 0:
@@ -567,7 +636,9 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                 "algorithmic_bytes_per_step": int(alg_bytes), "bytes_per_base": round(alg_bytes / max(n_bases, 1), 4),
-                "time_ms": round(pipe_ms, 3), "time": "HIP events around all kernels of a step (s2k_timing_total(0)), averaged over the timed steps",
+                "time_ms": round(pipe_ms, 3), "time": "HIP events around all kernels of a step (s2k_timing_total(0)), averaged over the timed steps of the "
+                                                      "one-context run (with two contexts the calls overlap: a call's events would include the other's kernels)",
+                "frac_at_value": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                 "kernel": "tile_minimizer_kernel<%d,%s>" % (args.l, "hpc" if mode == pkg.HashMode.Hpc else "regular"),
                 "kernel_ms": round(min_ms, 3), "kernel_bytes": int(kern_bytes),
                 "kernel_frac": round(kern_bytes / (min_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kminmer_kernel_ms": round(km_ms, 3),
@@ -681,6 +752,12 @@ def main():
             "value": round(value, 2), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "contexts": 2 if two_ctx is not None else 1,
+            "one_context": {"value": round(tot_bases * args.steps / dt_one / 1e9, 2), "ms_per_step": round(dt_one / args.steps * 1e3, 3),
+                            "what": "the same K steps through ONE context: every call waits for the one before it (the host looks at a call's counts before it "
+                                    "enqueues the next).  'value' alternates the steps between two contexts -- two caller streams, two sets of output arrays, "
+                                    "the same input -- so that the tail of a call runs beside the first chunk of the next; roofline.* and per_rank are taken "
+                                    "from this one-context run (kernel times unperturbed)"},
             "config": dict({"workload": "%s, HashMode::%s, l=%d k=%d d=%g; inputs resident in HBM" % (
                 wl_text, "Hpc" if mode == pkg.HashMode.Hpc else "Regular", args.l, args.k, args.density),
                 "name": {"c2": "BASELINE configs[1]", "ont": "BASELINE configs[2]", "hifi": "BASELINE configs[3]"}[args.workload], "mode": args.mode,

@@ -35,7 +35,8 @@ extern "C" {
  * are NULL when their count is 0; device-resident read tables are validated on the device (S2K_ERR_INVALID_ARG /
  * S2K_ERR_READ_TOO_LONG from s2k_extract_device, s2k_sync and s2k_hpc_device*); S2K_ERR_NON_ASCII is no longer returned;
  * + s2k_trim, s2k_density_for_bound, S2K_FLAG_LEGACY_PATH; s2k_counts.path tells the descriptor path (0) from the legacy one (2).
- * (Round 4 only ADDED two benchmark helpers, s2k_synth_hifi_lengths / s2k_synth_hifi_device: no existing entry point or struct changed, the version stays 2.)
+ * (Round 4 only ADDED entry points -- the benchmark helpers s2k_synth_hifi_lengths / s2k_synth_hifi_device, and s2k_chain_after: no existing entry point or
+ * struct changed, the version stays 2.)
  * A binding must refuse a library whose s2k_abi_version() differs from the header it was built against. */
 #define S2K_ABI_VERSION 2
 
@@ -132,6 +133,12 @@ s2k_ctx *s2k_create(int device, s2k_status *status);
 void s2k_destroy(s2k_ctx *ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
 s2k_status s2k_set_stream(s2k_ctx *ctx, void *hip_stream);
+/* Double buffering with two contexts on one device (a loop over many device-resident batches): after s2k_chain_after(b, a) the minimizer
+ * kernels of b's calls wait for the minimizer kernels of a's most recent call, nothing else does -- so the tail of a's call (its last
+ * k-min-mer kernel, the totals, the host's look at the counts) runs beside the first chunk of b's, and two persistent kernels never compete
+ * for the device.  Chain both ways (a after b, b after a) and alternate the calls from ONE host thread.  prev = NULL removes the link;
+ * remove it before prev is destroyed.  Results do not depend on it. */
+s2k_status s2k_chain_after(s2k_ctx *ctx, s2k_ctx *prev);
 /* s2k_extract cuts a call into sub-batches of whole reads of about `bases` bases each (default 2^29; 0 restores it) and
  * pipelines them: H2D of one, kernels of the previous, D2H of the one before run side by side.  Results do not depend
  * on it. */

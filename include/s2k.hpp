@@ -75,6 +75,12 @@ class Engine { // one per thread and device (like one KminmersIterator per threa
     Engine &operator=(const Engine &) = delete;
     ~Engine() { s2k_destroy(ctx_); }
 
+    // double buffering with two engines on one device (s2k_chain_after): this engine's minimizer kernels wait for those of prev's most recent
+    // call; chain both ways, alternate the calls from one thread; nullptr unlinks (do so before prev is destroyed)
+    void chain_after(Engine *prev) {
+        s2k_status st = s2k_chain_after(ctx_, prev ? prev->ctx_ : nullptr);
+        if (st != S2K_OK) throw Error(st, s2k_strerror(st));
+    }
     // bases per sub-batch of extract(): H2D / kernels / D2H of consecutive sub-batches overlap (0 = default, 2^29)
     void set_host_batch(uint64_t bases) {
         s2k_status st = s2k_set_host_batch(ctx_, bases);

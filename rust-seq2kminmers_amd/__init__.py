@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libs2k.so")
 ABI_VERSION = 2  # include/s2k.h S2K_ABI_VERSION this mirror was written against
 
 ABI_SYMBOLS = [
-    "s2k_trim", "s2k_density_for_bound", "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_set_host_batch", "s2k_strerror",
+    "s2k_trim", "s2k_density_for_bound", "s2k_abi_version", "s2k_device_count", "s2k_create", "s2k_destroy", "s2k_set_stream", "s2k_chain_after", "s2k_set_host_batch", "s2k_strerror",
     "s2k_last_error", "s2k_hash_bound", "s2k_extract", "s2k_result_free", "s2k_extract_device", "s2k_sync",
     "s2k_hpc_device", "s2k_hpc_device_ex", "s2k_count_device", "s2k_partition_device", "s2k_synth_bases_device", "s2k_synth_hifi_lengths", "s2k_synth_hifi_device", "s2k_last_kernel_ms", "s2k_enable_timing", "s2k_timing_total", "s2k_fastx_open", "s2k_fastx_next", "s2k_fastx_close", "s2k_run_file", "s2k_fastx_parse_device",
 ]
@@ -106,6 +106,7 @@ def load_library(path=None):
     L.s2k_destroy.argtypes = [C.c_void_p]
     L.s2k_destroy.restype = None
     L.s2k_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.s2k_chain_after.argtypes = [C.c_void_p, C.c_void_p]
     L.s2k_set_host_batch.argtypes = [C.c_void_p, C.c_uint64]
     L.s2k_set_host_batch.restype = C.c_int
     L.s2k_strerror.restype = C.c_char_p
@@ -199,6 +200,11 @@ class Engine:
 
     def set_stream(self, hip_stream_handle):
         self._check(self.lib.s2k_set_stream(self.ctx, C.c_void_p(int(hip_stream_handle))))
+
+    def chain_after(self, prev):
+        """Double buffering with two engines on one device: this engine's minimizer kernels wait for those of `prev`'s most recent call (and
+        nothing else does), so the tail of one call runs beside the first chunk of the next.  Chain both ways and alternate the calls; None unlinks."""
+        self._check(self.lib.s2k_chain_after(self.ctx, prev.ctx if prev is not None else None))
 
     def set_host_batch(self, bases):
         """Bases per sub-batch of `extract` (host buffers): H2D / kernels / D2H of consecutive sub-batches overlap."""

@@ -179,6 +179,9 @@ struct s2k_ctx {
     hipStream_t s_in = nullptr, s_out = nullptr;  // s2k_extract: H2D of the next / D2H of the previous sub-batch
     hipStream_t s_km = nullptr;                   // descriptor path: scan + k-min-mer kernel of chunk c run here, beside the minimizer kernel of chunk c+1
     std::vector<hipEvent_t> chunk_ev;             // fork / per-chunk / join events of that pipeline (no timing)
+    s2k_ctx *chain_prev = nullptr;                // s2k_chain_after: this context's minimizer kernels wait for tiles_done of that one
+    hipEvent_t tiles_done = nullptr;              // recorded behind the last minimizer kernel of a call (created on first use)
+    bool tiles_done_valid = false;
     uint32_t desc_chunks = 0;                     // chunks of tiles per call: 0 = default (6 for Hpc modes, 8 otherwise; S2K_DESC_CHUNKS overrides; 1 = no overlap)
     uint32_t lookback_giveups = 0;                // HpcSimd calls that were run again because a look-back gave up; two make the pre-pass the default of the context
     bool force_full_runs = false;                 // S2K_FULL_RUNS=1 (A/B, tests): HpcSimd counts the runs of every read in a pre-pass instead of looking back from tile to tile
@@ -434,6 +437,10 @@ s2k_status enqueue(s2k_ctx *ctx) {
         S2K_TRY(launch_read_table(c.d_read_off, n_reads, n_bases, n_tiles, &ctx->d_counts->bad_input, tile_read0,
                                   use_desc ? (unsigned long long *)d_agg : nullptr, agg_pack(0, 0, 0, 0, true, true), st),
                 "read table kernel");
+        // s2k_chain_after: this call's minimizer kernels start when those of the other context's call have ended (the launches above
+        // -- a memset, the read table -- need not wait)
+        if (ctx->chain_prev && ctx->chain_prev->tiles_done_valid) S2K_TRY(hipStreamWaitEvent(st, ctx->chain_prev->tiles_done, 0), "stream wait (chain)");
+        if (!ctx->tiles_done) S2K_TRY(hipEventCreateWithFlags(&ctx->tiles_done, hipEventDisableTiming), "event create");
         Sem sem = c.sem;
         sem.read_runs = nullptr;
         // HpcSimd: the tail rule needs the run count of the whole read.  Default: the tiles tell each other (Sem::tile_heads, a
@@ -473,6 +480,8 @@ s2k_status enqueue(s2k_ctx *ctx) {
                 S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, nullptr,
                                                nullptr, nullptr, ctx->d_counts, &dz, 0, st),
                         "tiled minimizer kernel");
+                S2K_TRY(hipEventRecord(ctx->tiles_done, st), "event");
+                ctx->tiles_done_valid = true;
                 if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
                 if (tm) S2K_TRY(hipEventRecord(ctx->ev[3], st), "event");
                 S2K_TRY(launch_desc_scan(0, n_tiles, dz, d_scan, ctx->d_counts, st), "tile word scan");
@@ -518,6 +527,8 @@ s2k_status enqueue(s2k_ctx *ctx) {
                     S2K_TRY(launch_desc_scan(T0, T1, dz, d_scan, ctx->d_counts, s2), "tile word scan");
                     S2K_TRY(launch_desc_kminmers(T0, T1, n_tiles, n_reads, dz, rec, ctx->d_counts, s2), "k-min-mer kernel");
                 }
+                S2K_TRY(hipEventRecord(ctx->tiles_done, st), "event");
+                ctx->tiles_done_valid = true;
                 if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
                 if (tm) S2K_TRY(hipEventRecord(ctx->ev[4], s2), "event");
                 // join: what follows in the caller's stream (finalize, the next call) comes after the last k-min-mer kernel
@@ -536,6 +547,8 @@ s2k_status enqueue(s2k_ctx *ctx) {
         S2K_TRY(launch_tile_minimizers(c.d_bases, c.d_read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor,
                                        tile_rec_off, tile_cnt, mn_cnt, ctx->d_counts, nullptr, 0, st),
                 "tiled minimizer kernel");
+        S2K_TRY(hipEventRecord(ctx->tiles_done, st), "event");
+        ctx->tiles_done_valid = true;
         if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
         S2K_TRY(launch_scan_u32(tile_cnt, n_tiles, tile_goff, scan_tmp, 0, st), "scan");
         S2K_TRY(launch_scan_u32(mn_cnt, n_reads, mn_off, scan_tmp, 0, st), "scan");
@@ -733,6 +746,7 @@ void s2k_destroy(s2k_ctx *ctx) {
     ctx->outbuf2.release();
     ctx->count_tab.release();
     if (ctx->s_km) (void)hipStreamDestroy(ctx->s_km);
+    if (ctx->tiles_done) (void)hipEventDestroy(ctx->tiles_done);
     for (hipEvent_t e : ctx->chunk_ev) (void)hipEventDestroy(e);
     if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
     if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
@@ -753,6 +767,13 @@ s2k_status s2k_set_stream(s2k_ctx *ctx, void *hip_stream) {
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
+    return S2K_OK;
+}
+
+s2k_status s2k_chain_after(s2k_ctx *ctx, s2k_ctx *prev) {
+    if (!ctx || prev == ctx) return S2K_ERR_INVALID_ARG;
+    if (prev && prev->device != ctx->device) return S2K_ERR_INVALID_ARG;
+    ctx->chain_prev = prev;
     return S2K_OK;
 }
 

@@ -1253,3 +1253,66 @@ def test_fuzz_standalone_hpc_short():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_hpc.py"), "77", "200"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "0 mismatches" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
+
+
+def test_two_chained_contexts_alternate(oracle):
+    """s2k_chain_after: two contexts chained both ways and fed alternately with DIFFERENT batches (different sizes, both scalar modes, several chunks
+    each) give what each batch gives alone; unlinking and destroying one context leaves the other usable."""
+    import torch
+
+    rng = np.random.default_rng(15)
+    dev = torch.device("cuda", 0)
+    batches = []
+    for n_reads, rl in ((260, 30000), (90, 52000), (400, 9000)):
+        reads = [rand_read(rng, int(rl + rng.integers(-500, 500)), hp=0.2) for _ in range(n_reads)]
+        bases, off = pkg.pack_reads(reads)
+        batches.append((bases, off, torch.from_numpy(bases).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev)))
+    os.environ["S2K_DESC_CHUNKS"] = "3"  # (read when a context is created: every call below is a three-chunk pipeline)
+    try:
+        a, b = pkg.Engine(0), pkg.Engine(0)
+    finally:
+        del os.environ["S2K_DESC_CHUNKS"]
+    a.chain_after(b)
+    b.chain_after(a)
+    with pytest.raises(pkg.S2kError):
+        a.chain_after(a)
+
+    def mk(n_reads, cap):
+        t = {"km_off": torch.zeros(n_reads + 1, dtype=torch.int64, device=dev), "hash": torch.zeros(cap, dtype=torch.int64, device=dev),
+             "start": torch.zeros(cap, dtype=torch.int32, device=dev), "end": torch.zeros(cap, dtype=torch.int32, device=dev),
+             "rev": torch.zeros(cap, dtype=torch.uint8, device=dev)}
+        o = pkg.DeviceOut()
+        o.km_capacity = cap
+        o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+        return t, o
+
+    for mode in (1, 0):
+        refs = [oracle.batch(bb[0], bb[1], 31, 10, 0.01, mode) for bb in batches]
+        pending = []  # (engine, tensors, batch index)
+        for i in range(9):
+            e = a if i % 2 == 0 else b
+            j = i % 3
+            bases, off, d_b, d_o = batches[j]
+            t, o = mk(len(off) - 1, refs[j]["n"] + 8)
+            e.extract_device(d_b.data_ptr(), d_o.data_ptr(), len(off) - 1, len(bases), 31, 10, 0.01, mode, o, sync=False)
+            # (a context finishes its own previous call before it takes the next one: that call's tensors may go now)
+            pending = [p for p in pending if p[0] is not e]
+            pending.append((e, t, j))
+            if i >= 7:  # the last call of each context: checked in full
+                c = e.sync()
+                ref = refs[j]
+                assert c["n_kminmers"] == ref["n"] and c["path"] == 0
+                assert (t["hash"][:ref["n"]].cpu().numpy().view(np.uint64) == ref["hash"]).all()
+                for f in ("start", "end"):
+                    assert (t[f][:ref["n"]].cpu().numpy().view(np.uint32) == ref[f]).all(), f
+                assert (t["rev"][:ref["n"]].cpu().numpy() == ref["rev"]).all() and (t["km_off"].cpu().numpy().view(np.uint64) == ref["km_off"]).all()
+    a.sync()
+    b.sync()
+    b.chain_after(None)
+    a.chain_after(None)
+    a.close()
+    bases, off, d_b, d_o = batches[0]
+    t, o = mk(len(off) - 1, refs[0]["n"] + 8)
+    c = b.extract_device(d_b.data_ptr(), d_o.data_ptr(), len(off) - 1, len(bases), 31, 10, 0.01, 0, o, sync=True)
+    assert c["n_kminmers"] == refs[0]["n"]
+    b.close()
