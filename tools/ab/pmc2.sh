@@ -6,7 +6,7 @@ args="$1"; shift
 for f in "$@"; do
   out=$GRAFT_REPO_ROOT/gpurun_out/pmc2_$(basename $f .so)
   rm -rf $out
-  S2K_LIB=$GRAFT_REPO_ROOT/$f S2K_DESC_CHUNKS=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-other-mode --verify-reads 0 $args > $out.log 2>&1 || echo "failed $f"
+  S2K_LIB=$GRAFT_REPO_ROOT/$f S2K_DESC_CHUNKS=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --contexts 1 --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-other-mode --verify-reads 0 $args > $out.log 2>&1 || echo "failed $f"
   python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)

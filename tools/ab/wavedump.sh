@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 args="$1"; shift
 for f in "$@"; do
   b=$(basename $f .so)
-  S2K_LIB=$GRAFT_REPO_ROOT/$f S2K_DESC_CHUNKS=1 S2K_DEBUG_SKIP=32 S2K_DEBUG_WAVE_DUMP=$GRAFT_REPO_ROOT/gpurun_out/waves_$b.txt timeout -k 10 200 python bench.py --no-cpu-baseline --no-end-to-end --no-other-mode --verify-reads 0 --steps 1 --warmup 0 $args 2>&1 | grep "dbg\|value" | cut -c1-300
+  S2K_LIB=$GRAFT_REPO_ROOT/$f S2K_DESC_CHUNKS=1 S2K_DEBUG_SKIP=32 S2K_DEBUG_WAVE_DUMP=$GRAFT_REPO_ROOT/gpurun_out/waves_$b.txt timeout -k 10 200 python bench.py --contexts 1 --no-cpu-baseline --no-end-to-end --no-other-mode --verify-reads 0 --steps 1 --warmup 0 $args 2>&1 | grep "dbg\|value" | cut -c1-300
   python3 - <<PY
 import collections
 rows = [tuple(map(int, l.split())) for l in open("$GRAFT_REPO_ROOT/gpurun_out/waves_$b.txt")]

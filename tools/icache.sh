@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQC_TC_INST_REQ SQ_IFETCH SQC_ICACHE_BUSY_CYCLES SQ_BUSY_CYCLES" "InstrFetchLatency" "LdsLatency"; do
   i=$((i+1))
-  S2K_DESC_CHUNKS=1 timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --verify-reads 0 > $out/p$i.log 2>&1 || echo "set $i failed"
+  S2K_DESC_CHUNKS=1 timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --contexts 1 --steps 1 --warmup 1 --no-cpu-baseline --verify-reads 0 > $out/p$i.log 2>&1 || echo "set $i failed"
 done
 python3 - <<PY
 import csv, glob, collections

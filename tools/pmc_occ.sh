@@ -9,7 +9,7 @@ for b in 2 3; do
  i=0
  for set in "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_BUSY_CYCLES" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  S2K_DEBUG_BLOCKS_PER_CU=$b timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/b${b}_$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --verify-reads 0 > $out/b${b}_$i.log 2>&1 || echo "b=$b set $i failed"
+  S2K_DEBUG_BLOCKS_PER_CU=$b timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/b${b}_$i -- python3 $GRAFT_REPO_ROOT/bench.py --contexts 1 --steps 1 --warmup 1 --no-cpu-baseline --verify-reads 0 > $out/b${b}_$i.log 2>&1 || echo "b=$b set $i failed"
  done
 done
 python3 - <<PY

@@ -9,7 +9,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for mode in hpc regular; do
-  args="--mode $mode --no-other-mode --no-cpu-baseline --no-end-to-end --verify-reads 0"
+  args="--mode $mode --contexts 1 --no-other-mode --no-cpu-baseline --no-end-to-end --verify-reads 0"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$mode/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $args > $out/$mode.stats.log 2>&1 || echo "stats pass failed ($mode)"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
@@ -27,7 +27,7 @@ for mode in ("hpc", "regular"):
     for f in glob.glob(out + "/%s/stats/*/*kernel_stats.csv" % mode):
         rows = list(csv.DictReader(open(f)))
     with open(out + "/%s_kernel_stats.csv" % mode, "w") as o:
-        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --mode %s --no-other-mode --no-cpu-baseline --verify-reads 0\n" % mode)
+        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --mode %s --contexts 1 --no-other-mode --no-cpu-baseline --verify-reads 0\n" % mode)
         o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
         for r in rows:
             n = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]

@@ -12,7 +12,7 @@ mkdir -p $out
 rm -f $GRAFT_REPO_ROOT/rust-seq2kminmers_amd/csrc/*.o && make -s -C $GRAFT_REPO_ROOT/rust-seq2kminmers_amd/csrc KNOBS=1 -j8 libs2k.so > /dev/null 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 for skip in 0 1 4 128 64 16; do
-  S2K_DESC_CHUNKS=1 S2K_DEBUG_SKIP=$skip timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/s$skip -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --verify-reads 0 > $out/s$skip.log 2>&1 || echo "skip=$skip failed"
+  S2K_DESC_CHUNKS=1 S2K_DEBUG_SKIP=$skip timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/s$skip -- python3 $GRAFT_REPO_ROOT/bench.py --contexts 1 --steps 1 --warmup 1 --no-cpu-baseline --verify-reads 0 > $out/s$skip.log 2>&1 || echo "skip=$skip failed"
 done
 python3 - <<PY
 import csv, glob, collections
