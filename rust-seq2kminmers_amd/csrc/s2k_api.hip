@@ -345,7 +345,10 @@ s2k_status enqueue(s2k_ctx *ctx) {
     // a quarter of the issue slots and some LDS free).  A chunk is at least a few tiles per resident wave.
     uint32_t n_chunks = 1;
     if (use_desc) {
-        n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? 6u : 8u); // measured: profiles/r03_ab_chunks.txt
+        // measured: profiles/r03_ab_chunks.txt (one context: more chunks = a smaller exposed tail, fewer = fewer chunk boundaries) and, for a chained
+        // context, profiles/r04_chained_chunks.txt: its tail runs beside the other context's minimizer kernels anyway, so the Hpc modes take two
+        // chunks (the Regular-family modes, whose k-min-mer kernel costs the minimizer kernel beside it more, still do best with eight)
+        n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? (ctx->chain_prev ? 2u : 6u) : 8u);
         const uint64_t min_chunk = ctx->desc_chunks ? 64 : 12 * 3072; // tiles: a dozen per resident wave (a forced count -- tests -- only needs 64)
         if ((uint64_t)n_chunks * min_chunk > n_tiles) n_chunks = (uint32_t)(n_tiles / min_chunk);
         if (n_chunks < 1) n_chunks = 1;
