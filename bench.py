@@ -13,8 +13,11 @@ Workloads (BASELINE.json configs):
       c2 run also reports its rate (and that of configs[4], 1 Mbp contigs at d = 0.001) under "other_configs".
 Bases are generated in HBM by the library's splitmix64 generator (rank r generates exactly its part of the one
 global stream).  A "step" is one pass of the whole hot path (s2k_extract_device: tile index + minimizer kernel + scans +
-k-min-mer kernel) over the resident batch.  Reads shard across GPUs with no data-path collective; the only cross-GPU
-traffic is an all-reduce of the count vector (RCCL).
+k-min-mer kernel) over the resident batch.  The K timed steps are measured twice, each time between a barrier + device synchronisation: through
+ONE context (every call waits for the one before it: `one_context`, and the source of roofline.* and per_rank), and alternating between TWO
+contexts chained with s2k_chain_after (two sets of output arrays, the same input) -- the double buffering of a loop over many batches, in which
+the tail of a call runs beside the first chunk of the next: that is `value` (--contexts 1 makes `value` the one-context figure).  Reads shard
+across GPUs with no data-path collective; the only cross-GPU traffic is an all-reduce of the count vector (RCCL).
 
 Launch: `python bench.py --gpus N` starts N rank processes itself (fresh children, before anything touches the GPU);
 under torchrun / torch.distributed.run (WORLD_SIZE set) it is one rank and --gpus must equal WORLD_SIZE.
