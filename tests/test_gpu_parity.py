@@ -1286,8 +1286,8 @@ def test_two_chained_contexts_alternate(oracle):
         o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
         return t, o
 
-    for mode in (1, 0):
-        refs = [oracle.batch(bb[0], bb[1], 31, 10, 0.01, mode) for bb in batches]
+    for mode in (1, 0, 3, 2):  # Hpc, Regular, HpcSimd (tile words + look-back), Simd
+        refs = [oracle.batch(bb[0], bb[1], 31, 10, 0.01, OMODE[mode]) for bb in batches]
         pending = []  # (engine, tensors, batch index)
         for i in range(9):
             e = a if i % 2 == 0 else b
@@ -1312,7 +1312,8 @@ def test_two_chained_contexts_alternate(oracle):
     a.chain_after(None)
     a.close()
     bases, off, d_b, d_o = batches[0]
-    t, o = mk(len(off) - 1, refs[0]["n"] + 8)
+    ref0 = oracle.batch(bases, off, 31, 10, 0.01, OMODE[0])
+    t, o = mk(len(off) - 1, ref0["n"] + 8)
     c = b.extract_device(d_b.data_ptr(), d_o.data_ptr(), len(off) - 1, len(bases), 31, 10, 0.01, 0, o, sync=True)
-    assert c["n_kminmers"] == refs[0]["n"]
+    assert c["n_kminmers"] == ref0["n"]
     b.close()
