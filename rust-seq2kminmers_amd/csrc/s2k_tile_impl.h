@@ -182,6 +182,27 @@ __device__ __forceinline__ uint32_t select_nth_32_lut(uint32_t w, uint32_t n) {
     c = __popc(w & 0xFFu);   if (n >= c) { n -= c; r += 8;  w >>= 8; }
     return r + reinterpret_cast<lds_cu8>((uint32_t)SEL8_OFF)[8u * (w & 0xFFu) + n];
 }
+// a * b + c for a, b < 2^24 as v_mad_u32_u24.  The compiler turns plain index arithmetic of this shape -- and __umul24(a, b) + c as well -- into
+// v_mad_u64_u32 with a 64-bit result nobody reads: a register pair more, and 3.37 instead of 3.10 issue cycles at three waves per SIMD
+// (tools/experiments/valu_rate.hip; the 64-bit and multiply instructions are NOT quarter rate on gfx950: v_mul_lo_u32, v_mul_hi_u32, v_lshl_add_u64 3.10).
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+// x / Tq for a hash position x < 64 Tq, Tq = 16 np, np in {1, 3, 5, 7, 9}: (x >> 4) / np by a 16-bit reciprocal (rcp = 65536 / np + 1:
+// exact while (x >> 4) (rcp np - 65536) < 65536, i.e. for all x < 2^16).  One 24-bit multiply and two shifts instead of the 64-bit
+// multiply-add pair the compiler made of __umulhi with a scalar operand.
+__device__ __forceinline__ uint32_t div_tq(uint32_t x, uint32_t rcp) { return __umul24(x >> 4, rcp) >> 16; }
+// x / TILE_T for x < 20 000 (a tile-relative offset): one 24-bit multiply and a shift (3641 / 2^19 = 1 / 144.0002; checked for every x below 20 000)
+static_assert(TILE_T == 144, "div_tile_t's reciprocal is that of 144");
+__device__ __forceinline__ uint32_t div_tile_t(uint32_t x) { return __umul24(x, 3641u) >> 19; }
+// bits [0, v) of a word: none for v <= 0, all for v >= 32 (v_med3_i32, v_bfm_b32, compare, select)
+__device__ __forceinline__ uint32_t bits_below(int v) {
+    const int t = v < 0 ? 0 : (v > 32 ? 32 : v);
+    const uint32_t m = (1u << ((uint32_t)t & 31u)) - 1u;
+    return t == 32 ? 0xFFFFFFFFu : m;
+}
 // Seed look-ups of the hot loop.  The two 2 KiB tables sit at LDS byte offsets 0 (IN pairs) and 2048 (OUT
 // pairs); the kernel has no static LDS, so the dynamic region starts at 0 (checked at kernel entry).  The byte
 // offset of a base's entries is formed ONCE, when the base enters the window, by one v_lshlrev_b32_sdwa (byte
@@ -495,7 +516,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         uint64_t sp = bpos0;
         for (uint64_t c0 = 0;; c0 += 64) {
             if (sp > t0 && sp < t0 + tile_len) {
-                const uint32_t rel = (uint32_t)(sp - t0), o = rel / TILE_T, i = rel - o * TILE_T;
+                const uint32_t rel = (uint32_t)(sp - t0), o = div_tile_t(rel), i = rel - __umul24(o, (uint32_t)TILE_T);
                 atomicOr(&S.fm[o][i >> 5], 1u << (i & 31u));
             }
             if ((uint64_t)r0 + 1 + c0 + 64 > (uint64_t)r1) break; // wave-uniform: all starts up to r1 covered
@@ -510,7 +531,8 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     S2K_STAMP(13); // compaction: read-start marks
     // 2. lane chunk -> registers
     uint32_t c[36];
-    const uint4 *src = reinterpret_cast<const uint4 *>(D + TILE_T * lane);
+    const uint32_t lane_off = __umul24((uint32_t)TILE_T, (uint32_t)lane);
+    const uint4 *src = reinterpret_cast<const uint4 *>(D + lane_off);
 #pragma unroll
     for (int p = 0; p < 9; p++) {
         uint4 v = src[p];
@@ -524,13 +546,13 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         if (forced0) fmk[0] |= 1u; // the tile starts a read
         prevw = prev_byte0 << 24;
     } else {
-        prevw = (uint32_t)D[TILE_T * lane - 1] << 24;
+        prevw = (uint32_t)D[lane_off - 1] << 24;
     }
     const uint32_t last_raw = bcast(c[35] >> 24, 63); // last raw byte of a full tile
     // the 128 staged look-ahead bytes serve the first round of the run-head search after the tile; read them
     // before the buffer is compacted in place (lanes 0..31, 4 bytes each)
     const uint32_t la_word = lane < 32 ? *reinterpret_cast<const uint32_t *>(D + TILE_BASES + 4 * lane) : 0u;
-    const int vb = (int)tile_len - TILE_T * lane;      // valid bytes in this lane's chunk (may be <=0 or >=144)
+    const int vb = (int)tile_len - (int)lane_off;      // valid bytes in this lane's chunk (may be <=0 or >=144)
     const bool partial = tile_len < (uint32_t)TILE_BASES;
     // 3. pass 1: SWAR "differs from its predecessor" per byte -> four flags per dword -> natural-order masks
     uint32_t pair7 = 0;
@@ -578,7 +600,8 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         S.hl[lane] = 63; // hash lanes past the last head
         wave_sync();
         if (cnt) {
-            for (uint32_t q = (base + tq - 1) / tq; q * tq < base + cnt && q < 64; q++) S.hl[q] = (uint8_t)lane;
+            const uint32_t rcp_tq = need <= 1 ? 65537u : need <= 3 ? 21846u : need <= 5 ? 13108u : need <= 7 ? 9363u : 7282u; // see div_tq
+            for (uint32_t q = div_tq(base + tq - 1, rcp_tq); __umul24(q, tq) < base + cnt && q < 64; q++) S.hl[q] = (uint8_t)lane;
         }
     }
     // all lanes hold their raw chunk in registers now -> the buffer may be overwritten in place
@@ -667,16 +690,6 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     return R;
 }
 
-// bits [0, v) of a word: none for v <= 0, all for v >= 32 (v_med3_i32, v_bfm_b32, compare, select)
-__device__ __forceinline__ uint32_t bits_below(int v) {
-    const int t = v < 0 ? 0 : (v > 32 ? 32 : v);
-    const uint32_t m = (1u << ((uint32_t)t & 31u)) - 1u;
-    return t == 32 ? 0xFFFFFFFFu : m;
-}
-// x / Tq for a hash position x < 64 Tq, Tq = 16 np, np in {1, 3, 5, 7, 9}: (x >> 4) / np by a 16-bit reciprocal (rcp = 65536 / np + 1:
-// exact while (x >> 4) (rcp np - 65536) < 65536, i.e. for all x < 2^16).  One 24-bit multiply and two shifts instead of the 64-bit
-// multiply-add pair the compiler made of __umulhi with a scalar operand.
-__device__ __forceinline__ uint32_t div_tq(uint32_t x, uint32_t rcp) { return __umul24(x >> 4, rcp) >> 16; }
 
 // Back-map of one Hpc hit: tile-relative raw offsets of run heads x and x + l (x < R; x + l may be one of the
 // run heads that follow the tile).  The owner raw lane of a head is the last o with hbase[o] <= head; S.hl
@@ -693,10 +706,11 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
         const uint32_t q = div_tq(head, rcpTq);
         uint32_t lo = S.hl[q];
         const uint32_t hi = q < 63 ? S.hl[q + 1] : 63u;
-        // three candidates beyond lo at once; a wider bracket (long homopolymers: raw lanes without heads) loops
-        const uint32_t a1 = S.hbase[lo + 1 > 63 ? 63 : lo + 1], a2 = S.hbase[lo + 2 > 63 ? 63 : lo + 2], a3 = S.hbase[lo + 3 > 63 ? 63 : lo + 3];
-        uint32_t o = lo + (uint32_t)(lo + 1 <= hi && a1 <= head) + (uint32_t)(lo + 2 <= hi && a2 <= head) + (uint32_t)(lo + 3 <= hi && a3 <= head);
-        while (o == lo + 3 && o < hi && S.hbase[o + 1] <= head) o++, lo++;
+        // two candidates beyond lo at once (a hash lane of 112 heads spans at most two raw lanes of ~105, three when they are short); a wider
+        // bracket (long homopolymers: raw lanes without heads) loops
+        const uint32_t a1 = S.hbase[lo + 1 > 63 ? 63 : lo + 1], a2 = S.hbase[lo + 2 > 63 ? 63 : lo + 2];
+        uint32_t o = lo + (uint32_t)(lo + 1 <= hi && a1 <= head) + (uint32_t)(lo + 2 <= hi && a2 <= head);
+        while (o == lo + 2 && o < hi && S.hbase[o + 1] <= head) o++, lo++;
         return o;
     };
     auto decode = [](const uint32_t (&w)[5], uint32_t n) { // raw offset (inside the lane's chunk) of the lane's n-th run head
@@ -715,26 +729,30 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
     const uint32_t lo1 = owner(x);
     const uint32_t ln = lo1 < 63 ? lo1 + 1 : 63u; // the raw lane after it
     const uint32_t hb1 = S.hbase[lo1], hbn = lo1 < 63 ? S.hbase[ln] : R, hbnn = lo1 < 62 ? S.hbase[lo1 + 2 > 63 ? 63 : lo1 + 2] : R;
+    // (mad24: as plain index arithmetic the row addresses and lane offsets became v_mad_u64_u32)
+    const uint32_t *fm0 = &S.fm[0][0];
+    const uint32_t *r1 = fm0 + mad24(lo1, 5u, 0u), *rn = fm0 + mad24(ln, 5u, 0u);
     uint32_t w1[5], wn[5];
 #pragma unroll
     for (int d = 0; d < 5; d++) {
-        w1[d] = S.fm[lo1][d];
-        wn[d] = S.fm[ln][d];
+        w1[d] = r1[d];
+        wn[d] = rn[d];
     }
     const uint32_t n1 = x - hb1;
-    raw_x = TILE_T * lo1 + decode(w1, n1);
+    raw_x = mad24(lo1, (uint32_t)TILE_T, decode(w1, n1));
     const uint32_t m2 = n1 + l; // head x + l, counted from the first head of lane lo1
     const bool same = m2 < hbn - hb1, next = !same && m2 - (hbn - hb1) < hbnn - hbn;
     uint32_t w2[5];
 #pragma unroll
     for (int d = 0; d < 5; d++) w2[d] = same ? w1[d] : wn[d];
-    uint32_t re = TILE_T * (same ? lo1 : ln) + decode(w2, same ? m2 : m2 - (hbn - hb1));
+    uint32_t re = mad24(same ? lo1 : ln, (uint32_t)TILE_T, decode(w2, same ? m2 : m2 - (hbn - hb1)));
     if (y_in && !same && !next) { // the next lane holds fewer than l heads beyond x: search for head x + l like for head x
         const uint32_t lo2 = owner(y);
+        const uint32_t *r3 = fm0 + mad24(lo2, 5u, 0u);
         uint32_t w3[5];
 #pragma unroll
-        for (int d = 0; d < 5; d++) w3[d] = S.fm[lo2][d];
-        re = TILE_T * lo2 + decode(w3, y - S.hbase[lo2]);
+        for (int d = 0; d < 5; d++) w3[d] = r3[d];
+        re = mad24(lo2, (uint32_t)TILE_T, decode(w3, y - S.hbase[lo2]));
     }
     const uint32_t hx = y - R; // only meaningful when !y_in; validated hits guarantee hx < halo_n
     const uint32_t he = S.halo_pos[(!y_in && hx < halo_n) ? hx : 0];
@@ -793,7 +811,7 @@ __device__ __forceinline__ void publish_tile_heads(uint32_t *W, uint64_t t, cons
     } else if (last_start >= t0 + tile_len) {
         word = HW_VALID; // a read starts exactly where the tile ends: nothing continues past it
     } else { // run heads from the last read start on: nh - rank of that (forced) head
-        const uint32_t rel = (uint32_t)(last_start - t0), o = rel / TILE_T, wi = rel % TILE_T;
+        const uint32_t rel = (uint32_t)(last_start - t0), o = div_tile_t(rel), wi = rel - __umul24(o, (uint32_t)TILE_T);
         uint32_t c = S.hbase[o];
         uint32_t f[5];
 #pragma unroll
@@ -832,9 +850,10 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     //     end of the stream) is the one external boundary.
     const uint32_t wclr = HPC ? (sem.keep_last ? l - 1 : l) : l - 1; // Hpc drops the last l-mer of a read (src/nthash_hpc.rs:265-267)
     const uint32_t rcpTq = Tq == 112u ? 9363u : Tq == 48u ? 21846u : Tq == 80u ? 13108u : Tq == 144u ? 7282u : 65537u; // 65536 / (Tq / 16) + 1 for Tq / 16 in {7, 3, 5, 9, 1}: see div_tq (a division costs ~25 instructions per tile)
+    const uint32_t tql = __umul24(Tq, (uint32_t)lane); // first hash position of this lane
     uint32_t vm[5]; // validated hit mask of this lane
     {
-        int vc = (int)nh - (int)(Tq * lane); // hash positions of this lane that exist
+        int vc = (int)nh - (int)tql; // hash positions of this lane that exist
 #pragma unroll
         for (int d = 0; d < 5; d++) {
             vm[d] = raw[d] & bits_below(vc - 32 * d);
@@ -857,7 +876,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             if (internal || (external && lane == first_ext)) {
                 if constexpr (HPC) {
                     if (bpos < tile_end) { // rank of the forced run head at raw offset bpos - t0
-                        const uint32_t rel = (uint32_t)(bpos - t0), o = rel / TILE_T, wi = rel % TILE_T;
+                        const uint32_t rel = (uint32_t)(bpos - t0), o = div_tile_t(rel), wi = rel - __umul24(o, (uint32_t)TILE_T);
                         const uint32_t g = wi >> 5;
                         uint32_t c = S.hbase[o];
                         for (uint32_t gg = 0; gg < g; gg++) c += __popc(S.fm[o][gg]);
@@ -910,7 +929,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                             // ... and only if the tile HAS a hit among the positions the rule would take away beyond the plain clear,
                             // [HB - w - 16, HB - w - 1]: three times in four it has none, and the count does not matter
                             const int32_t hb0 = (int32_t)bcast((uint32_t)HB, 0);
-                            const int lo = hb0 - (int)wclr - 16 - (int)(Tq * lane), hi = hb0 - (int)wclr - 1 - (int)(Tq * lane); // lane-local, inclusive
+                            const int lo = hb0 - (int)wclr - 16 - (int)tql, hi = hb0 - (int)wclr - 1 - (int)tql; // lane-local, inclusive
                             uint32_t inwin = 0;
                             if (hi >= 0 && lo < (int)Tq) {
 #pragma unroll
@@ -961,7 +980,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                 const int32_t hbz = (int32_t)bcast((uint32_t)HB, z);
                 const int wz = (int)wclr + (int)bcast(wextra, z);
                 if (hbz - wz >= (int)nh) continue; // (wave-uniform: the next read starts so far behind the tile that the range holds none of its positions -- most tiles)
-                const int lo = hbz - wz - (int)(Tq * lane), hi = hbz - 1 - (int)(Tq * lane); // lane-local, inclusive
+                const int lo = hbz - wz - (int)tql, hi = hbz - 1 - (int)tql; // lane-local, inclusive
                 if (hi >= 0 && lo < (int)Tq) {
 #pragma unroll
                     for (int d = 0; d < 5; d++) {
@@ -983,7 +1002,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                     const int z = __builtin_ctzll(ex);
                     ex &= ex - 1;
                     const uint32_t hx = bcast((uint32_t)(pstart - t0), z); // tile-local position of that read's only l-mer
-                    const int rel = (int)hx - (int)(Tq * lane);
+                    const int rel = (int)hx - (int)tql;
                     if (rel >= 0 && rel < (int)Tq) {
 #pragma unroll
                         for (int d = 0; d < 5; d++) // static indices: vm[] must stay in registers
@@ -1043,7 +1062,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
         for (uint32_t i = 0; i <= nb; i++) { // wave-uniform trip count
             uint32_t below = N;
             if (i < nb) {
-                const int lim = S.hb[i] - (int)(Tq * lane); // lane-local bits [0, lim) lie below boundary i
+                const int lim = S.hb[i] - (int)tql; // lane-local bits [0, lim) lie below boundary i
                 uint32_t c = 0;
 #pragma unroll
                 for (int d = 0; d < 5; d++) {
@@ -1075,7 +1094,10 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
         const uint32_t m_first = bcast(mine, 0), m_last = bcast(mine, (int)nb);
         uint32_t wfix = (uint32_t)lane <= nb && mine > K1 ? mine - K1 : 0u; // windows of a segment that starts a read in (or at the start of) the tile
         if (lane == 0 && dep) wfix = 0;                                         // (the first segment's depend on p)
-        const uint32_t Cfix = bcast(wave_incl_scan(wfix, lane), 63);
+        // (only lanes 0 .. nb hold a window count: one read start per tile as a rule -- two readlanes instead of a scan over the wave)
+        uint32_t Cfix;
+        if (nb <= 2u) Cfix = bcast(wfix, 0) + (nb >= 1u ? bcast(wfix, 1) : 0u) + (nb >= 2u ? bcast(wfix, 2) : 0u);
+        else Cfix = bcast(wave_incl_scan(wfix, lane), 63);
         const bool pass = dep && nb == 0 && !ext_at_end;
         const uint32_t q_out = ext_at_end ? 0u : (m_last < K1 ? m_last : K1);
         if (lane == 0) {
@@ -1180,7 +1202,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                     const uint32_t later = rw & (pm & ~((2u << bit) - 1u));
                     const uint32_t hvk = CAPP == 16 ? ((bit & 16) ? cap1 : cap0) : ((bit & 16) ? ((bit & 8) ? cap3 : cap2) : ((bit & 8) ? cap1 : cap0));
                     if (SINGLE || (k >= b0 && k < b0 + LISTCAP)) {
-                        S.list[k - b0] = (uint16_t)((Tq * lane + 32 * d + bit) | (later ? 0x8000u : 0u));
+                        S.list[k - b0] = (uint16_t)((tql + 32 * d + bit) | (later ? 0x8000u : 0u));
                         if (!later && !(sem.dbg_skip & 16)) rec.hash[base + k] = hvk;
                     }
                     k++;
@@ -1221,18 +1243,19 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
         if (b0 + (uint32_t)LISTCAP >= N) issue_next(N, base);
         // one hit per lane: tile-local hash position -> stream positions of the l-mer's first base and of the last base that
         // belongs to it
-        auto backmap = [&](uint32_t x, uint64_t &p, uint64_t &e1) {
+        // (tile-relative 32-bit offsets: the descriptor path's record is tile-relative, only the legacy path adds t0)
+        auto backmap = [&](uint32_t x, uint32_t &p, uint32_t &e1) {
             if constexpr (HPC) {
                 uint32_t rp = 0, re = 0;
                 // Hpc: st[p+l] - 1 (src/nthash_hpc.rs:281; head x + l exists: the hit survived validation);
                 // HpcSimd: st[p+l-1], the start of the last run (src/nthash_hpc_simd.rs:64)
                 const uint32_t back = sem.end_kind == 2 ? 1u : 0u;
                 hpc_rawpos2(S, x, l - back, nh, halo_n, Tq, rcpTq, rp, re);
-                e1 = t0 + re - (1u - back);
-                p = t0 + rp;
+                e1 = re - (1u - back);
+                p = rp;
             } else {
-                p = t0 + x;
-                e1 = p + l - 1; // src/lib.rs:226
+                p = x;
+                e1 = x + l - 1; // src/lib.rs:226
             }
         };
         auto rounds = [&](auto many_c) {
@@ -1246,18 +1269,19 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             uint32_t x = 0, rid = 0;
             if (act) x = S.list[kk] & 0x3FFFu;
             S2K_STAMP(8); // round: list read
-            uint64_t p = 0, e1 = 0; // stream position of the l-mer start; position of the last base that belongs to it
-            if (act) backmap(x, p, e1);
+            uint32_t prel = 0, erel = 0; // tile-relative: the l-mer's first base; the last base that belongs to it (may lie far behind the tile)
+            if (act) backmap(x, prel, erel);
             S2K_STAMP(9); // round: back-map
             if constexpr (DESC) {
                 if (act) {
                     // tile-relative record: where the read starts is looked up from the tile's segment list by the k-min-mer kernel
-                    const uint64_t span = e1 - p;
-                    if (span > (uint64_t)REC_SPAN_MAX) counts->need_legacy = 1; // (a homopolymer stretch of > 262 kbp inside one l-mer)
-                    const uint32_t sp = span > (uint64_t)REC_SPAN_MAX ? REC_SPAN_MAX : (uint32_t)span;
-                    if (!(sem.dbg_skip & 16)) rec.j[base + b0 + kk] = (uint32_t)(p - t0) | (sp << 14);
+                    const uint32_t span = erel - prel;
+                    if (span > (uint32_t)REC_SPAN_MAX) counts->need_legacy = 1; // (a homopolymer stretch of > 262 kbp inside one l-mer)
+                    const uint32_t sp = span > (uint32_t)REC_SPAN_MAX ? (uint32_t)REC_SPAN_MAX : span;
+                    if (!(sem.dbg_skip & 16)) rec.j[base + b0 + kk] = prel | (sp << 14);
                 }
             } else {
+            const uint64_t p = t0 + prel, e1 = t0 + erel;
             if (act) {
                 uint64_t rstart;
                 if constexpr (!MANY) {

@@ -122,6 +122,22 @@ KERNEL(bitop3, A_BITOP3, "memory")
 KERNEL(align2, A_ALIGN2, "memory")
 KERNEL(hstep, A_HSTEP, "vcc", "v40", "v41", "v42")
 
+// round 4: the 64-bit and multiply instructions the compiler makes of index arithmetic
+#define A_MAD64(i) "v_mad_u64_u32 v[40:41], s[20:21], %" #i ", %8, v[40:41]\n\t"
+#define A_LSHLADD64(i) "v_lshl_add_u64 v[40:41], v[40:41], 2, v[42:43]\n\t"
+#define A_CMP64(i) "v_cmp_lt_u64_e32 vcc, v[40:41], v[42:43]\n\t"
+#define A_MULHI(i) "v_mul_hi_u32 %" #i ", %" #i ", %8\n\t"
+#define A_MOV64(i) "v_mov_b64 v[40:41], v[42:43]\n\t"
+#define A_MED3(i) "v_med3_i32 %" #i ", %" #i ", %8, %9\n\t"
+#define A_BFM(i) "v_bfm_b32 %" #i ", %" #i ", %8\n\t"
+KERNEL(mad64, A_MAD64, "v40", "v41", "s20", "s21")
+KERNEL(lshladd64, A_LSHLADD64, "v40", "v41", "v42", "v43")
+KERNEL(cmp64, A_CMP64, "vcc", "v40", "v41", "v42", "v43")
+KERNEL(mulhi, A_MULHI, "memory")
+KERNEL(mov64, A_MOV64, "v40", "v41", "v42", "v43")
+KERNEL(med3, A_MED3, "memory")
+KERNEL(bfm, A_BFM, "memory")
+
 // LDS table look-ups as in the hash loop: ds_read_b64 of one of 4 entries per lane
 __global__ __launch_bounds__(256) void k_ldsb64(uint32_t *out, uint64_t *cyc, int iters, uint32_t s) {
     __shared__ uint2 tab[512];
@@ -179,7 +195,9 @@ int main() {
                     {"v_lshlrev_b32", k_lshl, 32}, {"v_and_b32", k_and_, 32}, {"v_sub_u32", k_sub, 32}, {"v_max_u32", k_max, 32},
                     {"v_lshlrev_b64", k_lshl64, 32}, {"v_mad_u32_u24", k_madu24, 32}, {"v_bfi_b32", k_bfi, 32},
                     {"v_xor_b32_sdwa", k_xorsdwa, 32}, {"xor+xor (2)", k_xorxor, 64}, {"v_sub_co_u32", k_subco, 32}, {"sub_co+cnd+addc (3)", k_track3, 96},
-                    {"v_bitop3_b32 (3 regs)", k_bitop3, 32}, {"v_alignbit (2 regs)", k_align2, 32}, {"hash step mix (6)", k_hstep, 192}};
+                    {"v_bitop3_b32 (3 regs)", k_bitop3, 32}, {"v_alignbit (2 regs)", k_align2, 32}, {"hash step mix (6)", k_hstep, 192},
+                    {"v_mad_u64_u32", k_mad64, 32}, {"v_lshl_add_u64", k_lshladd64, 32}, {"v_cmp_lt_u64", k_cmp64, 32}, {"v_mul_hi_u32", k_mulhi, 32},
+                    {"v_mov_b64", k_mov64, 32}, {"v_med3_i32", k_med3, 32}, {"v_bfm_b32", k_bfm, 32}};
     const int iters = 20000;
     printf("%-22s", "cycles/wave-instr/SIMD");
     for (int wps : {1, 2, 3, 4, 8}) printf("  %dw/SIMD", wps);
