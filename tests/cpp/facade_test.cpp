@@ -26,6 +26,24 @@ int main(int argc, char **argv) {
             for (s2k::Minimizer m : s2k::NtHashSIMDIterator(eng, seq, std::stoul(argv[2]), bound)) std::printf("M 2 %zu %zu %u\n", m.start, m.end, m.hash);
             for (s2k::Minimizer m : s2k::NtHashHPCSIMDIterator(eng, seq, std::stoul(argv[2]), bound)) std::printf("M 3 %zu %zu %u\n", m.start, m.end, m.hash);
         }
+        { // two engines linked for double buffering (s2k_chain_after through the facade): linking, self-linking refused, unlinking
+            s2k::Engine other(0);
+            eng.chain_after(&other);
+            other.chain_after(&eng);
+            try {
+                eng.chain_after(&eng);
+                return 5;
+            } catch (const s2k::Error &e) {
+                if (e.status != S2K_ERR_INVALID_ARG) return 6;
+            }
+            s2k::KminmersIterator again(other, seq, std::stoul(argv[2]), std::stoul(argv[3]), std::stod(argv[4]), (s2k::HashMode)std::stoi(argv[5]));
+            size_t n_again = 0, n_first = 0;
+            for (s2k::KminmerHash km : again) n_again += 1 + 0 * km.start;
+            for (s2k::KminmerHash km : it) n_first += 1 + 0 * km.start;
+            if (n_again != n_first) return 7;
+            eng.chain_after(nullptr);
+            other.chain_after(nullptr);
+        }
         // error behaviour: k == 0 panics in the reference (src/lib.rs:246), throws here
         try {
             s2k::KminmersIterator bad(eng, seq, 31, 0, 0.01, s2k::HashMode::Regular);
