@@ -210,7 +210,15 @@ def main():
     if dist is not None:
         # proof that the process group really spans N ranks on N devices: every rank contributes (rank, device index, PCI bus id)
         props = torch.cuda.get_device_properties(dev)
-        words = [rank, local_rank, hash(getattr(props, "pci_bus_id", local_rank)) & 0x7FFFFFFF]
+        # the device's identity as the DRIVER reports it: uuid, else PCI domain:bus:device; never hash() (randomised per process) and never the
+        # rank's own input (local_rank), which would make two ranks on one device look distinct
+        dev_id = str(getattr(props, "uuid", "") or "")
+        if not dev_id or set(dev_id) <= set("0-"):
+            dev_id = "pci:%s:%s:%s" % (getattr(props, "pci_domain_id", "?"), getattr(props, "pci_bus_id", "?"), getattr(props, "pci_device_id", "?"))
+        import hashlib
+
+        dg = hashlib.sha256(dev_id.encode()).digest()  # (deterministic across processes; travels with the other words, over RCCL or gloo)
+        words = [rank, local_rank, int.from_bytes(dg[:7], "little"), int.from_bytes(dg[7:14], "little")]
         rccl_error = None
         if red_dev.type == "cuda":
             try:
@@ -233,7 +241,8 @@ def main():
         backend_text = args.backend if args.backend != "nccl" else ("nccl (RCCL)" if rccl_error is None else "gloo (RCCL unusable: %s)" % rccl_error)
         collective = {"backend": backend_text, "world_size_seen": dist.get_world_size(),
                       "ranks": [int(v[0]) for v in allv], "devices": [int(v[1]) for v in allv],
-                      "distinct_devices": len({(int(v[1]), int(v[2])) for v in allv}), "visible_devices": n_dev,
+                      "device_ids": ["%014x%014x" % (int(v[2]), int(v[3])) for v in allv], "device_id_of": "sha256(uuid or pci domain:bus:device)[:14]",
+                      "distinct_devices": len({(int(v[2]), int(v[3])) for v in allv}), "visible_devices": n_dev,
                       "device_name": props.name}
         assert collective["world_size_seen"] == args.gpus and sorted(collective["ranks"]) == list(range(args.gpus)), collective
         if not args.single_device:

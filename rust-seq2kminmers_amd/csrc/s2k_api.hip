@@ -206,6 +206,13 @@ struct s2k_ctx {
     std::shared_ptr<HostPool> host_pool = std::make_shared<HostPool>(); // result arrays of s2k_extract
 };
 
+// Every live context, so that s2k_destroy can take the context it destroys out of the chains of the others (s2k_chain_after): a link
+// to a destroyed context must never be followed.  One mutex; contexts are created and destroyed rarely.
+namespace {
+std::mutex g_ctx_mu;
+std::vector<s2k_ctx *> g_live_ctx;
+} // namespace
+
 // context internals for the other translation units of the library (declared in s2k_hostcopy.h)
 namespace s2k {
 HostStager &ctx_stager(s2k_ctx *c) { return c->stager; }
@@ -731,12 +738,28 @@ s2k_ctx *s2k_create(int device, s2k_status *status) {
         if (atoi(e) >= 1 && atoi(e) <= 64) ctx->desc_chunks = (uint32_t)atoi(e);
     if (const char *e = getenv("S2K_TRACE")) ctx->trace = atoi(e) != 0;
     if (const char *e = getenv("S2K_FULL_RUNS")) ctx->force_full_runs = atoi(e) != 0;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        g_live_ctx.push_back(ctx);
+    }
     *status = S2K_OK;
     return ctx;
 }
 
 void s2k_destroy(s2k_ctx *ctx) {
     if (!ctx) return;
+    { // no other context may keep a link to this one (s2k_chain_after): its next call would wait on an event that no longer exists
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        for (size_t i = 0; i < g_live_ctx.size();) {
+            if (g_live_ctx[i] == ctx) {
+                g_live_ctx[i] = g_live_ctx.back();
+                g_live_ctx.pop_back();
+                continue;
+            }
+            if (g_live_ctx[i]->chain_prev == ctx) g_live_ctx[i]->chain_prev = nullptr;
+            i++;
+        }
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->ws.release();

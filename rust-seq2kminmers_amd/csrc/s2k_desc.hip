@@ -193,8 +193,11 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
     __shared__ int32_t s_adj[DK_WAVES][META_SEGS];
     __shared__ uint32_t s_segb[DK_WAVES][META_SEGS];
     __shared__ uint32_t s_jcar[DK_WAVES][DK_KMAX];
-    __shared__ uint32_t s_cum[DK_WAVES][64];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: per-tile values are scalar
+    // cumulative minimizer counts of the 63 tiles before this one (round trip 2 only): they share the ring's upper 64 entries, which the rounds
+    // overwrite afterwards (the entries below DK_KMAX take the minimizers found with them) -- 6.5 -> 5.5 KiB per block, so that two blocks fit
+    // beside the persistent minimizer kernel's block whatever that one's rows cost (s2k_tile_impl.h: HpcLds)
+    uint32_t *const s_cum_w = reinterpret_cast<uint32_t *>(&s_ring[w][DK_KMAX]);
     const uint64_t t = tile_begin + (uint64_t)blockIdx.x * DK_WAVES + w;
     if (t >= tile_end) return; // whole waves leave together; no block-level barrier below
     // ---- round trip 1: everything whose address depends on nothing loaded -- the words of this tile and of the 63 before it,
@@ -253,23 +256,23 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
     //      before it.  The counts of the 63 tiles before this one are in the lanes already.
     if (p_in) { // wave-uniform
         const uint32_t Nl = lane >= 1 ? (uint32_t)((agw >> 28) & 0x3FFFu) : 0u; // lane i >= 1: minimizers of tile t - i
-        s_cum[w][lane] = dk_incl_scan(Nl);                                        // ... of tiles t-1 .. t-i together
+        s_cum_w[lane] = dk_incl_scan(Nl);                                        // ... of tiles t-1 .. t-i together
         wave_sync();
         if ((uint32_t)lane < p_in) {
             const uint32_t q = (uint32_t)lane;
             int ti = 1;
 #pragma nounroll // (the first tile back as a rule: unrolled 63 times this search was most of the kernel's code)
-            while (ti < 64 && s_cum[w][ti] <= q) ti++; // first tile back whose cumulative count exceeds q
+            while (ti < 64 && s_cum_w[ti] <= q) ti++; // first tile back whose cumulative count exceeds q
             uint64_t u = 0;
             uint32_t idx = 0, Nu = 0;
             bool found = false;
             if (ti < 64 && (uint64_t)ti <= t) {
                 u = t - ti;
-                Nu = s_cum[w][ti] - s_cum[w][ti - 1];
-                idx = Nu - 1 - (q - s_cum[w][ti - 1]);
+                Nu = s_cum_w[ti] - s_cum_w[ti - 1];
+                idx = Nu - 1 - (q - s_cum_w[ti - 1]);
                 found = true;
             } else { // more than 63 tiles back (very sparse minimizers): walk
-                uint32_t rem = q - s_cum[w][63];
+                uint32_t rem = q - s_cum_w[63];
                 u = t >= 63 ? t - 63 : 0;
                 while (u > 0) {
                     u--;

@@ -82,7 +82,12 @@ constexpr int MAX_L_TILED = 64;
 #ifndef S2K_JOBCAP
 #define S2K_JOBCAP 32
 #endif
-constexpr int LISTCAP = S2K_LISTCAP;                           // hits handled per dense batch
+#ifndef S2K_BM2
+#define S2K_BM2 1 // back-map v2: per-lane rows {flag words, prefix, cumulative word counts} + a directory of every 64th run head (see HpcLds)
+#endif
+constexpr int LISTCAP_REG = S2K_LISTCAP;                       // hits handled per dense batch (Regular: 184 +- 13 per tile)
+constexpr int LISTCAP_HPC = S2K_BM2 ? 192 : S2K_LISTCAP;       // ... Hpc: 137 +- 11 per tile of uniform ACGT; the 128 bytes pay for the wider rows of the back-map
+template <bool HPC> constexpr int listcap() { return HPC ? LISTCAP_HPC : LISTCAP_REG; }
 constexpr int JOBCAP = S2K_JOBCAP;                             // queued hash re-derivations per flush
 #ifndef S2K_REG_LA
 #define S2K_REG_LA 1
@@ -99,18 +104,35 @@ template <bool DESC> constexpr int stores_per_round() { return DESC ? 1 : 3; }
 static_assert(NBL == META_SEGS, "TileMeta keeps NBL segment starts");
 constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
 
+#if S2K_BM2
+// Back-map data of a tile, written by hpc_compact.  Everything a hit needs to find the raw offset of a run head x is TWO small reads
+// away from x itself: sd[x >> 6] names the raw lane that owns head 64 (x >> 6) -- the owner of x is that lane or the next one unless a lane
+// holds fewer than 64 heads --, and that lane's row says how many heads lie before it (prefix) and before each of its flag words (cum),
+// so that ONE flag word is fetched and searched (sel8).  (Rounds 2-4: a hint per hash lane, a search over the prefixes, two whole rows of
+// five words and a popcount walk over them per head -- nine dependent LDS round trips and ~250 instructions per round of 64 hits.)
+constexpr int ROW_W = 6, ROW_PFX = 4, ROW_CUM = 5, N_ROWS = 66, SD_SHIFT = 6;
+struct HpcLds {
+    uint32_t row[N_ROWS][ROW_W]; // raw lane o: words 0-3 = run-head flags of its bytes 0..127 (bit i of word g <-> byte 32 g + i), word 4 = flags of bytes
+                                 // 128..143 | exclusive prefix of the lanes' head counts << 16, word 5 = heads in words 0..g, one byte per g = 0..3.
+                                 // Rows 64, 65: sentinels (prefix = R, the tile's head count)
+    uint32_t halo_pos[64];       // tile-relative raw offsets of the run heads that follow the tile
+    uint8_t sd[160];             // sd[m] = raw lane that owns run head 64 m (m <= (R - 1) / 64 <= 143)
+};
+static_assert(sizeof(HpcLds) % 16 == 0, "the tile buffer behind it is read 16 bytes at a time");
+#else
 struct HpcLds {
     uint32_t fm[64][5];      // run-head flags of the lane's 144 raw bytes, natural order: bit i of the 144-bit mask <-> raw byte i
     uint16_t hbase[64];      // exclusive prefix of per-lane run-head counts (<= 9216)
     uint32_t halo_pos[64];   // tile-relative raw offsets of the run heads that follow the tile
     uint8_t hl[64];          // raw lane that owns run head Tq*q (first head of hash lane q): search hint for the back-map
 };
+#endif
 struct NoHpcLds {};
 
 template <bool HPC>
 struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
     uint8_t buf[BUF_BYTES];
-    uint16_t list[LISTCAP];   // validated hits of the current batch: tile-local hash position (bits 0-13), ascending; bit 15 = hash must be re-derived
+    uint16_t list[listcap<HPC>()]; // validated hits of the current batch: tile-local hash position (bits 0-13), ascending; bit 15 = hash must be re-derived
     uint16_t jobx[JOBCAP];    // hits whose hash must be re-derived: tile-local position ...
     uint16_t jobslot[JOBCAP]; // ... and index of the hit among the tile's hits
     int16_t hb[NBL];         // read starts inside the tile, as hash-space positions (ascending; 0 .. TILE_BASES)
@@ -203,6 +225,29 @@ __device__ __forceinline__ uint32_t bits_below(int v) {
     const uint32_t m = (1u << ((uint32_t)t & 31u)) - 1u;
     return t == 32 ? 0xFFFFFFFFu : m;
 }
+#if S2K_BM2
+// heads of a raw lane before its flag word g (0 .. 4), from the lane's cum word (byte k = heads in words 0 .. k): byte g - 1, or 0 for g = 0 --
+// one v_perm_b32 whose selector picks a zero byte for g = 0
+__device__ __forceinline__ uint32_t heads_before_word(uint32_t cum, uint32_t g) {
+    return __builtin_amdgcn_perm(cum, 0u, g + 0x0C0C0C03u); // selector bytes 1-3: 0x0C = constant zero; byte 0: 3 -> zero (src1), 4 + k -> byte k of cum
+}
+// flag word of a raw lane that holds its n-th run head (0-based, n < heads of the lane): number of cum bytes <= n (the bytes ascend)
+__device__ __forceinline__ uint32_t word_of_head(uint32_t cum, uint32_t n) {
+    uint32_t g = 0;
+    asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc"
+        : "+v"(g)
+        : "v"(n), "v"(cum)
+        : "vcc");
+    return g;
+}
+#endif
 // Seed look-ups of the hot loop.  The two 2 KiB tables sit at LDS byte offsets 0 (IN pairs) and 2048 (OUT
 // pairs); the kernel has no static LDS, so the dynamic region starts at 0 (checked at kernel entry).  The byte
 // offset of a base's entries is formed ONCE, when the base enters the window, by one v_lshlrev_b32_sdwa (byte
@@ -517,7 +562,11 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         for (uint64_t c0 = 0;; c0 += 64) {
             if (sp > t0 && sp < t0 + tile_len) {
                 const uint32_t rel = (uint32_t)(sp - t0), o = div_tile_t(rel), i = rel - __umul24(o, (uint32_t)TILE_T);
+#if S2K_BM2
+                atomicOr(&S.row[o][i >> 5], 1u << (i & 31u));
+#else
                 atomicOr(&S.fm[o][i >> 5], 1u << (i & 31u));
+#endif
             }
             if ((uint64_t)r0 + 1 + c0 + 64 > (uint64_t)r1) break; // wave-uniform: all starts up to r1 covered
             const uint64_t ri = (uint64_t)r0 + 1 + c0 + 64 + lane;
@@ -540,7 +589,11 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     }
     uint32_t fmk[5];
 #pragma unroll
+#if S2K_BM2
+    for (int g = 0; g < 5; g++) fmk[g] = S.row[lane][g]; // forced heads
+#else
     for (int g = 0; g < 5; g++) fmk[g] = S.fm[lane][g]; // forced heads
+#endif
     uint32_t prevw;
     if (lane == 0) {
         if (forced0) fmk[0] |= 1u; // the tile starts a read
@@ -586,6 +639,23 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
             fmk[g] &= v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
         }
     }
+#if S2K_BM2
+    const uint32_t p0 = __popc(fmk[0]), p1 = p0 + __popc(fmk[1]), p2 = p1 + __popc(fmk[2]), p3 = p2 + __popc(fmk[3]);
+    uint32_t cnt = p3 + __popc(fmk[4]);
+    uint32_t incl = wave_incl_scan(cnt, lane);
+    uint32_t base = incl - cnt;
+    const uint32_t R = bcast(incl, 63);
+    { // the lane's row (HpcLds), three 8-byte stores; lanes 0 and 1 also leave the sentinels behind the last lane
+        uint2 *rw = reinterpret_cast<uint2 *>(&S.row[lane][0]);
+        rw[0] = make_uint2(fmk[0], fmk[1]);
+        rw[1] = make_uint2(fmk[2], fmk[3]);
+        rw[2] = make_uint2(fmk[4] | (base << 16), p0 | (p1 << 8) | (p2 << 16) | (p3 << 24));
+        if (lane < N_ROWS - 64) *reinterpret_cast<uint2 *>(&S.row[64 + lane][ROW_PFX]) = make_uint2(R << 16, 0u);
+        // directory: the raw lane that owns run head 64 m, for every m the lane's range [base, base + cnt) holds (at most three)
+        if (cnt)
+            for (uint32_t m = (base + (1u << SD_SHIFT) - 1u) >> SD_SHIFT; (m << SD_SHIFT) < base + cnt; m++) S.sd[m] = (uint8_t)lane;
+    }
+#else
     uint32_t cnt = __popc(fmk[0]) + __popc(fmk[1]) + __popc(fmk[2]) + __popc(fmk[3]) + __popc(fmk[4]);
     uint32_t incl = wave_incl_scan(cnt, lane);
     uint32_t base = incl - cnt;
@@ -604,6 +674,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
             for (uint32_t q = div_tq(base + tq - 1, rcp_tq); __umul24(q, tq) < base + cnt && q < 64; q++) S.hl[q] = (uint8_t)lane;
         }
     }
+#endif
     // all lanes hold their raw chunk in registers now -> the buffer may be overwritten in place
     wave_sync();
     S2K_STAMP(14); // compaction: chunk load + flags + scan
@@ -696,6 +767,56 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
 // brackets it to the raw lanes spanned by the head's hash lane.  Head x + l is found FROM head x: it lies l heads
 // further on, i.e. in the same raw lane or in the next one unless a lane holds fewer than l heads (long homopolymers:
 // those hits search again) -- round 2 ran two full searches side by side (~100 instructions each per round of 64 hits).
+#if S2K_BM2
+// Back-map of one Hpc hit (v2, see HpcLds): tile-relative raw offsets of run heads x and y = x + l (x < R; y may be one of the run heads
+// that follow the tile).  Four LDS round trips, both heads side by side: directory -> {prefix, cum} of the three candidate lanes ->
+// the one flag word that holds the head -> sel8.
+template <class WL>
+__device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l, uint32_t R, uint32_t halo_n,
+                                            uint32_t Tq, uint32_t rcpTq, uint32_t &raw_x, uint32_t &raw_e) {
+    (void)Tq;
+    (void)rcpTq;
+    typedef __attribute__((address_space(3))) const uint8_t *lds_cu8;
+    const uint32_t y = x + l;
+    const bool y_in = y < R;
+    const uint32_t yy = y_in ? y : x; // (a head of the tile either way; what it gives is not used when y lies behind the tile)
+    const uint32_t hx = y - R;        // index among the run heads that follow the tile; validated hits guarantee hx < halo_n then
+    const uint32_t he = S.halo_pos[(!y_in && hx < halo_n) ? hx : 0];
+    const uint32_t sd0 = (uint32_t)(uintptr_t)(lds_cu8)&S.sd[0], row0 = (uint32_t)(uintptr_t)(lds_cu8)&S.row[0][0];
+    // 1: the directory
+    const uint32_t ox0 = reinterpret_cast<lds_cu8>(sd0)[x >> SD_SHIFT], oy0 = reinterpret_cast<lds_cu8>(sd0)[yy >> SD_SHIFT];
+    // 2: {flags 128.. | prefix << 16, cum} of the lane the directory names and of the two after it (rows 64, 65 are sentinels)
+    typedef __attribute__((address_space(3))) const unsigned long long *lds_cu64;
+    typedef __attribute__((address_space(3))) const uint32_t *lds_cu32;
+    auto ld2 = [](uint32_t a) { // ds_read_b64
+        const unsigned long long v = *reinterpret_cast<lds_cu64>(a);
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    };
+    const uint32_t rx = mad24(ox0, 4u * ROW_W, row0), ry = mad24(oy0, 4u * ROW_W, row0);
+    const uint2 ax = ld2(rx + 4 * ROW_PFX), bx = ld2(rx + 4 * (ROW_PFX + ROW_W)), cx = ld2(rx + 4 * (ROW_PFX + 2 * ROW_W));
+    const uint2 ay = ld2(ry + 4 * ROW_PFX), by = ld2(ry + 4 * (ROW_PFX + ROW_W)), cy = ld2(ry + 4 * (ROW_PFX + 2 * ROW_W));
+    const bool sx = (bx.x >> 16) <= x, sy = (by.x >> 16) <= yy;
+    uint32_t rox = sx ? rx + 4 * ROW_W : rx, roy = sy ? ry + 4 * ROW_W : ry; // LDS address of the owner's row
+    uint2 px = sx ? bx : ax, py = sy ? by : ay;
+    if (__ballot((cx.x >> 16) <= x || (cy.x >> 16) <= yy)) { // (wave-uniform, rare: a raw lane with fewer than 64 run heads -- long homopolymers: walk on)
+        while ((*reinterpret_cast<lds_cu32>(rox + 4 * (ROW_PFX + ROW_W)) >> 16) <= x) rox += 4 * ROW_W;
+        while ((*reinterpret_cast<lds_cu32>(roy + 4 * (ROW_PFX + ROW_W)) >> 16) <= yy) roy += 4 * ROW_W;
+        px = ld2(rox + 4 * ROW_PFX);
+        py = ld2(roy + 4 * ROW_PFX);
+    }
+    // 3: the flag word that holds the head (word 4 carries the prefix above its 16 flags: a head's rank inside the word never reaches them)
+    const uint32_t nx = x - (px.x >> 16), ny = yy - (py.x >> 16);
+    const uint32_t gx = word_of_head(px.y, nx), gy = word_of_head(py.y, ny);
+    const uint32_t wx = *reinterpret_cast<lds_cu32>(rox + 4u * gx), wy = *reinterpret_cast<lds_cu32>(roy + 4u * gy);
+    // 4: the head's bit inside it
+    const uint32_t bx_ = select_nth_32_lut(wx, nx - heads_before_word(px.y, gx)), by_ = select_nth_32_lut(wy, ny - heads_before_word(py.y, gy));
+    // row address -> lane: (ro - row0) / 24, then x 144: one multiply by 6
+    raw_x = (rox - row0) * (uint32_t)(TILE_T / (4 * ROW_W)) + 32u * gx + bx_;
+    const uint32_t re = (roy - row0) * (uint32_t)(TILE_T / (4 * ROW_W)) + 32u * gy + by_;
+    raw_e = y_in ? re : he;
+}
+static_assert(TILE_T % (4 * ROW_W) == 0, "raw offset of a lane = its row offset times a whole number");
+#else
 template <class WL>
 __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l, uint32_t R, uint32_t halo_n,
                                             uint32_t Tq, uint32_t rcpTq, uint32_t &raw_x, uint32_t &raw_e) {
@@ -758,6 +879,18 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
     const uint32_t he = S.halo_pos[(!y_in && hx < halo_n) ? hx : 0];
     raw_e = y_in ? re : he;
 }
+#endif
+#if S2K_BM2
+// run heads of the tile before the raw byte at tile-relative offset rel (< TILE_BASES): prefix of its lane + heads of the lane's earlier
+// flag words + those of its own word below its bit -- two reads, one round trip
+template <class WL>
+__device__ __forceinline__ uint32_t heads_before_raw(const WL &S, uint32_t rel) {
+    const uint32_t o = div_tile_t(rel), wi = rel - __umul24(o, (uint32_t)TILE_T), g = wi >> 5;
+    const uint2 pc = *reinterpret_cast<const uint2 *>(&S.row[o][ROW_PFX]);
+    const uint32_t wd = S.row[o][g];
+    return (pc.x >> 16) + heads_before_word(pc.y, g) + __popc(wd & ((1u << (wi & 31u)) - 1u)); // (g = 4: wi & 31 < 16, the prefix bits are masked off)
+}
+#endif
 
 // HpcSimd without a second pass over the bases: run heads that the tiles before tile t hold of the read that continues into it.
 // Every tile publishes one word right after its compaction (publish_tile_heads): HW_VALID | count of its run heads that belong
@@ -811,6 +944,9 @@ __device__ __forceinline__ void publish_tile_heads(uint32_t *W, uint64_t t, cons
     } else if (last_start >= t0 + tile_len) {
         word = HW_VALID; // a read starts exactly where the tile ends: nothing continues past it
     } else { // run heads from the last read start on: nh - rank of that (forced) head
+#if S2K_BM2
+        const uint32_t c = heads_before_raw(S, (uint32_t)(last_start - t0));
+#else
         const uint32_t rel = (uint32_t)(last_start - t0), o = div_tile_t(rel), wi = rel - __umul24(o, (uint32_t)TILE_T);
         uint32_t c = S.hbase[o];
         uint32_t f[5];
@@ -821,6 +957,7 @@ __device__ __forceinline__ void publish_tile_heads(uint32_t *W, uint64_t t, cons
             const int v = (int)wi - 32 * gg; // bits of word gg that lie before the read start
             c += __popc(f[gg] & (v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u))));
         }
+#endif
         word = HW_VALID | (nh - c);
     }
     if (lane == 0) __hip_atomic_store(W + t, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -848,6 +985,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     //     before the next read, src/lib.rs:215-230; w = l run heads for Hpc: head x+l must exist in the
     //     same read, src/nthash_hpc.rs:265-267).  The first read start at or after the tile end (or the
     //     end of the stream) is the one external boundary.
+    constexpr int LISTCAP = listcap<HPC>();
     const uint32_t wclr = HPC ? (sem.keep_last ? l - 1 : l) : l - 1; // Hpc drops the last l-mer of a read (src/nthash_hpc.rs:265-267)
     const uint32_t rcpTq = Tq == 112u ? 9363u : Tq == 48u ? 21846u : Tq == 80u ? 13108u : Tq == 144u ? 7282u : 65537u; // 65536 / (Tq / 16) + 1 for Tq / 16 in {7, 3, 5, 9, 1}: see div_tq (a division costs ~25 instructions per tile)
     const uint32_t tql = __umul24(Tq, (uint32_t)lane); // first hash position of this lane
@@ -876,12 +1014,16 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             if (internal || (external && lane == first_ext)) {
                 if constexpr (HPC) {
                     if (bpos < tile_end) { // rank of the forced run head at raw offset bpos - t0
+#if S2K_BM2
+                        HB = (int32_t)heads_before_raw(S, (uint32_t)(bpos - t0)); // run heads before the forced one
+#else
                         const uint32_t rel = (uint32_t)(bpos - t0), o = div_tile_t(rel), wi = rel - __umul24(o, (uint32_t)TILE_T);
                         const uint32_t g = wi >> 5;
                         uint32_t c = S.hbase[o];
                         for (uint32_t gg = 0; gg < g; gg++) c += __popc(S.fm[o][gg]);
                         c += __popc(S.fm[o][g] & ((1u << (wi & 31u)) - 1u)); // run heads before the forced one
                         HB = (int32_t)c;
+#endif
                     } else { // first read start (or stream end) after the tile: count the run heads before it
                         HB = -1; // resolved below by the whole wave
                     }
@@ -1559,7 +1701,11 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         if (lane == 0) S.buf[HS_OFF - 1] = 0;
         if constexpr (HPC) {
 #pragma unroll
+#if S2K_BM2
+            for (int g2 = 0; g2 < 5; g2++) S.row[lane][g2] = 0; // read-start marks are OR-ed in by hpc_compact
+#else
             for (int g2 = 0; g2 < 5; g2++) S.fm[lane][g2] = 0; // read-start marks are OR-ed in by hpc_compact
+#endif
         }
         wave_sync();
         S2K_STAMP(0); // staging
@@ -1662,7 +1808,8 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         // with very many reads loads and counts in there: it waits for everything)
         {
             const bool many = (cr1 - cr0) > (uint32_t)(NBL - 2) || (sem.dbg_skip & 16) != 0; // (KNOBS builds: stores ablated)
-            const uint32_t last = N == 0 ? 0u : N - ((N - 1) / (uint32_t)LISTCAP) * (uint32_t)LISTCAP;
+            constexpr uint32_t LISTCAP = (uint32_t)listcap<HPC>();
+            const uint32_t last = N == 0 ? 0u : N - ((N - 1) / LISTCAP) * LISTCAP;
             stores_after_dma = many ? 0u : (uint32_t)stores_per_round<DESC>() * ((last + 63u) / 64u);
         }
         wave_sync(); // LDS of this wave is reused by the next tile

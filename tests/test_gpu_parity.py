@@ -1317,3 +1317,39 @@ def test_two_chained_contexts_alternate(oracle):
     c = b.extract_device(d_b.data_ptr(), d_o.data_ptr(), len(off) - 1, len(bases), 31, 10, 0.01, 0, o, sync=True)
     assert c["n_kminmers"] == ref0["n"]
     b.close()
+
+
+def test_destroying_a_chained_to_context_unlinks_the_survivor(oracle):
+    """s2k_destroy takes the destroyed context out of every chain (s2k_chain_after): the survivor, still 'chained' to it by the caller's
+    book-keeping, runs its next calls unchained instead of following a dangling link."""
+    import torch
+
+    rng = np.random.default_rng(16)
+    dev = torch.device("cuda", 0)
+    reads = [rand_read(rng, int(20000 + rng.integers(-300, 300)), hp=0.2) for _ in range(200)]
+    bases, off = pkg.pack_reads(reads)
+    d_b, d_o = torch.from_numpy(bases).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev)
+    a, b = pkg.Engine(0), pkg.Engine(0)
+    a.chain_after(b)
+    b.chain_after(a)
+    ref = oracle.batch(bases, off, 31, 10, 0.01, OMODE[1])
+    cap = ref["n"] + 8
+
+    def run(e):
+        t = {"km_off": torch.zeros(len(off), dtype=torch.int64, device=dev), "hash": torch.zeros(cap, dtype=torch.int64, device=dev),
+             "start": torch.zeros(cap, dtype=torch.int32, device=dev), "end": torch.zeros(cap, dtype=torch.int32, device=dev),
+             "rev": torch.zeros(cap, dtype=torch.uint8, device=dev)}
+        o = pkg.DeviceOut()
+        o.km_capacity = cap
+        o.km_off, o.hash, o.start, o.end, o.rev = (t[x].data_ptr() for x in ("km_off", "hash", "start", "end", "rev"))
+        c = e.extract_device(d_b.data_ptr(), d_o.data_ptr(), len(off) - 1, len(bases), 31, 10, 0.01, 1, o, sync=True)
+        assert c["n_kminmers"] == ref["n"]
+        assert (t["hash"][:ref["n"]].cpu().numpy().view(np.uint64) == ref["hash"]).all()
+        assert (t["km_off"].cpu().numpy().view(np.uint64) == ref["km_off"]).all()
+
+    run(a)
+    run(b)       # both have a recorded tiles_done event now
+    a.close()    # destroyed FIRST, while b is still chained to it
+    run(b)       # must not touch a's event
+    run(b)
+    b.close()
