@@ -82,11 +82,11 @@ constexpr int MAX_L_TILED = 64;
 #ifndef S2K_JOBCAP
 #define S2K_JOBCAP 32
 #endif
-#ifndef S2K_BM2
-#define S2K_BM2 1 // back-map v2: per-lane rows {flag words, prefix, cumulative word counts} + a directory of every 64th run head (see HpcLds)
+#ifndef S2K_REDERIVE_GROUP
+#define S2K_REDERIVE_GROUP 4 // bases a lane of a re-derivation quad fetches at a time (8 = all of them at once: measured equal, profiles/r05_ab_rederive.txt)
 #endif
 constexpr int LISTCAP_REG = S2K_LISTCAP;                       // hits handled per dense batch (Regular: 184 +- 13 per tile)
-constexpr int LISTCAP_HPC = S2K_BM2 ? 192 : S2K_LISTCAP;       // ... Hpc: 137 +- 11 per tile of uniform ACGT; the 128 bytes pay for the wider rows of the back-map
+constexpr int LISTCAP_HPC = 192;                                      // ... Hpc: 137 +- 11 per tile of uniform ACGT; the 128 bytes pay for the wider rows of the back-map
 template <bool HPC> constexpr int listcap() { return HPC ? LISTCAP_HPC : LISTCAP_REG; }
 constexpr int JOBCAP = S2K_JOBCAP;                             // queued hash re-derivations per flush
 #ifndef S2K_REG_LA
@@ -104,7 +104,6 @@ template <bool DESC> constexpr int stores_per_round() { return DESC ? 1 : 3; }
 static_assert(NBL == META_SEGS, "TileMeta keeps NBL segment starts");
 constexpr int NPRE = 10;                               // 16 B/lane loads that stage one tile + 128 B look-ahead
 
-#if S2K_BM2
 // Back-map data of a tile, written by hpc_compact.  Everything a hit needs to find the raw offset of a run head x is TWO small reads
 // away from x itself: sd[x >> 6] names the raw lane that owns head 64 (x >> 6) -- the owner of x is that lane or the next one unless a lane
 // holds fewer than 64 heads --, and that lane's row says how many heads lie before it (prefix) and before each of its flag words (cum),
@@ -119,14 +118,6 @@ struct HpcLds {
     uint8_t sd[160];             // sd[m] = raw lane that owns run head 64 m (m <= (R - 1) / 64 <= 143)
 };
 static_assert(sizeof(HpcLds) % 16 == 0, "the tile buffer behind it is read 16 bytes at a time");
-#else
-struct HpcLds {
-    uint32_t fm[64][5];      // run-head flags of the lane's 144 raw bytes, natural order: bit i of the 144-bit mask <-> raw byte i
-    uint16_t hbase[64];      // exclusive prefix of per-lane run-head counts (<= 9216)
-    uint32_t halo_pos[64];   // tile-relative raw offsets of the run heads that follow the tile
-    uint8_t hl[64];          // raw lane that owns run head Tq*q (first head of hash lane q): search hint for the back-map
-};
-#endif
 struct NoHpcLds {};
 
 template <bool HPC>
@@ -225,7 +216,6 @@ __device__ __forceinline__ uint32_t bits_below(int v) {
     const uint32_t m = (1u << ((uint32_t)t & 31u)) - 1u;
     return t == 32 ? 0xFFFFFFFFu : m;
 }
-#if S2K_BM2
 // heads of a raw lane before its flag word g (0 .. 4), from the lane's cum word (byte k = heads in words 0 .. k): byte g - 1, or 0 for g = 0 --
 // one v_perm_b32 whose selector picks a zero byte for g = 0
 __device__ __forceinline__ uint32_t heads_before_word(uint32_t cum, uint32_t g) {
@@ -247,7 +237,6 @@ __device__ __forceinline__ uint32_t word_of_head(uint32_t cum, uint32_t n) {
         : "vcc");
     return g;
 }
-#endif
 // Seed look-ups of the hot loop.  The two 2 KiB tables sit at LDS byte offsets 0 (IN pairs) and 2048 (OUT
 // pairs); the kernel has no static LDS, so the dynamic region starts at 0 (checked at kernel entry).  The byte
 // offset of a base's entries is formed ONCE, when the base enters the window, by one v_lshlrev_b32_sdwa (byte
@@ -562,11 +551,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         for (uint64_t c0 = 0;; c0 += 64) {
             if (sp > t0 && sp < t0 + tile_len) {
                 const uint32_t rel = (uint32_t)(sp - t0), o = div_tile_t(rel), i = rel - __umul24(o, (uint32_t)TILE_T);
-#if S2K_BM2
                 atomicOr(&S.row[o][i >> 5], 1u << (i & 31u));
-#else
-                atomicOr(&S.fm[o][i >> 5], 1u << (i & 31u));
-#endif
             }
             if ((uint64_t)r0 + 1 + c0 + 64 > (uint64_t)r1) break; // wave-uniform: all starts up to r1 covered
             const uint64_t ri = (uint64_t)r0 + 1 + c0 + 64 + lane;
@@ -589,11 +574,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     }
     uint32_t fmk[5];
 #pragma unroll
-#if S2K_BM2
     for (int g = 0; g < 5; g++) fmk[g] = S.row[lane][g]; // forced heads
-#else
-    for (int g = 0; g < 5; g++) fmk[g] = S.fm[lane][g]; // forced heads
-#endif
     uint32_t prevw;
     if (lane == 0) {
         if (forced0) fmk[0] |= 1u; // the tile starts a read
@@ -639,7 +620,6 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
             fmk[g] &= v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u));
         }
     }
-#if S2K_BM2
     const uint32_t p0 = __popc(fmk[0]), p1 = p0 + __popc(fmk[1]), p2 = p1 + __popc(fmk[2]), p3 = p2 + __popc(fmk[3]);
     uint32_t cnt = p3 + __popc(fmk[4]);
     uint32_t incl = wave_incl_scan(cnt, lane);
@@ -655,26 +635,6 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         if (cnt)
             for (uint32_t m = (base + (1u << SD_SHIFT) - 1u) >> SD_SHIFT; (m << SD_SHIFT) < base + cnt; m++) S.sd[m] = (uint8_t)lane;
     }
-#else
-    uint32_t cnt = __popc(fmk[0]) + __popc(fmk[1]) + __popc(fmk[2]) + __popc(fmk[3]) + __popc(fmk[4]);
-    uint32_t incl = wave_incl_scan(cnt, lane);
-    uint32_t base = incl - cnt;
-    const uint32_t R = bcast(incl, 63);
-#pragma unroll
-    for (int g = 0; g < 5; g++) S.fm[lane][g] = fmk[g];
-    S.hbase[lane] = base;
-    { // hint table for the back-map: hl[q] = raw lane that owns run head Tq*q (first head of hash lane q).  Raw lane
-      // o owns heads [base, base+cnt), i.e. the hash-lane starts q with base <= Tq*q < base+cnt: at most a few.
-        const uint32_t need = (R + 1023u) >> 10;
-        const uint32_t tq = 16u * (need <= 1 ? 1u : need <= 3 ? 3u : need <= 5 ? 5u : need <= 7 ? 7u : 9u);
-        S.hl[lane] = 63; // hash lanes past the last head
-        wave_sync();
-        if (cnt) {
-            const uint32_t rcp_tq = need <= 1 ? 65537u : need <= 3 ? 21846u : need <= 5 ? 13108u : need <= 7 ? 9363u : 7282u; // see div_tq
-            for (uint32_t q = div_tq(base + tq - 1, rcp_tq); __umul24(q, tq) < base + cnt && q < 64; q++) S.hl[q] = (uint8_t)lane;
-        }
-    }
-#endif
     // all lanes hold their raw chunk in registers now -> the buffer may be overwritten in place
     wave_sync();
     S2K_STAMP(14); // compaction: chunk load + flags + scan
@@ -694,7 +654,11 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const int i = (4 * d + b) & 31;
+#ifdef S2K_X1 // (timing experiment only, WRONG results: every lane stores into its own bank -- what do the scatter's bank conflicts cost?)
+                    const uint32_t a = ((gaddr & ~0x7Cu) | (((uint32_t)lane & 31u) << 2)) + (__popc(fmk[g] & (i == 31 ? 0xFFFFFFFFu : ((2u << i) - 1u))) & 3u);
+#else
                     const uint32_t a = gaddr + __popc(fmk[g] & (i == 31 ? 0xFFFFFFFFu : ((2u << i) - 1u))); // v_and + v_bcnt(+gaddr)
+#endif
                     if (!PARTIAL || 4 * d + b < vb) {
                         if (b == 0) asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(c[d]) : "memory");
                         if (b == 1) asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(hi) : "memory");
@@ -767,24 +731,34 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
 // brackets it to the raw lanes spanned by the head's hash lane.  Head x + l is found FROM head x: it lies l heads
 // further on, i.e. in the same raw lane or in the next one unless a lane holds fewer than l heads (long homopolymers:
 // those hits search again) -- round 2 ran two full searches side by side (~100 instructions each per round of 64 hits).
-#if S2K_BM2
 // Back-map of one Hpc hit (v2, see HpcLds): tile-relative raw offsets of run heads x and y = x + l (x < R; y may be one of the run heads
 // that follow the tile).  Four LDS round trips, both heads side by side: directory -> {prefix, cum} of the three candidate lanes ->
 // the one flag word that holds the head -> sel8.
+struct BmFirst { // what the first round trip of a hit's back-map brings: the directory entries of its two run heads and the position behind the tile
+    uint32_t x, yy, ox0, oy0, he;
+    bool y_in;
+};
 template <class WL>
-__device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l, uint32_t R, uint32_t halo_n,
-                                            uint32_t Tq, uint32_t rcpTq, uint32_t &raw_x, uint32_t &raw_e) {
-    (void)Tq;
-    (void)rcpTq;
+__device__ __forceinline__ BmFirst hpc_rawpos_first(const WL &S, uint32_t x, uint32_t l, uint32_t R, uint32_t halo_n) {
     typedef __attribute__((address_space(3))) const uint8_t *lds_cu8;
+    BmFirst f;
     const uint32_t y = x + l;
-    const bool y_in = y < R;
-    const uint32_t yy = y_in ? y : x; // (a head of the tile either way; what it gives is not used when y lies behind the tile)
-    const uint32_t hx = y - R;        // index among the run heads that follow the tile; validated hits guarantee hx < halo_n then
-    const uint32_t he = S.halo_pos[(!y_in && hx < halo_n) ? hx : 0];
-    const uint32_t sd0 = (uint32_t)(uintptr_t)(lds_cu8)&S.sd[0], row0 = (uint32_t)(uintptr_t)(lds_cu8)&S.row[0][0];
-    // 1: the directory
-    const uint32_t ox0 = reinterpret_cast<lds_cu8>(sd0)[x >> SD_SHIFT], oy0 = reinterpret_cast<lds_cu8>(sd0)[yy >> SD_SHIFT];
+    f.x = x;
+    f.y_in = y < R;
+    f.yy = f.y_in ? y : x;     // (a head of the tile either way; what it gives is not used when y lies behind the tile)
+    const uint32_t hx = y - R; // index among the run heads that follow the tile; validated hits guarantee hx < halo_n then
+    f.he = S.halo_pos[(!f.y_in && hx < halo_n) ? hx : 0];
+    const uint32_t sd0 = (uint32_t)(uintptr_t)(lds_cu8)&S.sd[0];
+    f.ox0 = reinterpret_cast<lds_cu8>(sd0)[x >> SD_SHIFT];
+    f.oy0 = reinterpret_cast<lds_cu8>(sd0)[f.yy >> SD_SHIFT];
+    return f;
+}
+template <class WL>
+__device__ __forceinline__ void hpc_rawpos_rest(const WL &S, const BmFirst &f, uint32_t &raw_x, uint32_t &raw_e) {
+    typedef __attribute__((address_space(3))) const uint8_t *lds_cu8;
+    const uint32_t x = f.x, yy = f.yy, ox0 = f.ox0, oy0 = f.oy0, he = f.he;
+    const bool y_in = f.y_in;
+    const uint32_t row0 = (uint32_t)(uintptr_t)(lds_cu8)&S.row[0][0];
     // 2: {flags 128.. | prefix << 16, cum} of the lane the directory names and of the two after it (rows 64, 65 are sentinels)
     typedef __attribute__((address_space(3))) const unsigned long long *lds_cu64;
     typedef __attribute__((address_space(3))) const uint32_t *lds_cu32;
@@ -815,72 +789,15 @@ __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l,
     const uint32_t re = (roy - row0) * (uint32_t)(TILE_T / (4 * ROW_W)) + 32u * gy + by_;
     raw_e = y_in ? re : he;
 }
-static_assert(TILE_T % (4 * ROW_W) == 0, "raw offset of a lane = its row offset times a whole number");
-#else
 template <class WL>
 __device__ __forceinline__ void hpc_rawpos2(const WL &S, uint32_t x, uint32_t l, uint32_t R, uint32_t halo_n,
                                             uint32_t Tq, uint32_t rcpTq, uint32_t &raw_x, uint32_t &raw_e) {
-    const uint32_t y = x + l;
-    const bool y_in = y < R;
     (void)Tq;
-    auto owner = [&](uint32_t head) { // last raw lane o with hbase[o] <= head
-        const uint32_t q = div_tq(head, rcpTq);
-        uint32_t lo = S.hl[q];
-        const uint32_t hi = q < 63 ? S.hl[q + 1] : 63u;
-        // two candidates beyond lo at once (a hash lane of 112 heads spans at most two raw lanes of ~105, three when they are short); a wider
-        // bracket (long homopolymers: raw lanes without heads) loops
-        const uint32_t a1 = S.hbase[lo + 1 > 63 ? 63 : lo + 1], a2 = S.hbase[lo + 2 > 63 ? 63 : lo + 2];
-        uint32_t o = lo + (uint32_t)(lo + 1 <= hi && a1 <= head) + (uint32_t)(lo + 2 <= hi && a2 <= head);
-        while (o == lo + 2 && o < hi && S.hbase[o + 1] <= head) o++, lo++;
-        return o;
-    };
-    auto decode = [](const uint32_t (&w)[5], uint32_t n) { // raw offset (inside the lane's chunk) of the lane's n-th run head
-        uint32_t g = 0, word = w[0];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const uint32_t c = __popc(word);
-            if (n >= c && g == (uint32_t)d) {
-                n -= c;
-                g++;
-                word = w[d + 1];
-            }
-        }
-        return 32 * g + (S2K_SEL8 ? select_nth_32_lut(word, n) : select_nth_32(word, n));
-    };
-    const uint32_t lo1 = owner(x);
-    const uint32_t ln = lo1 < 63 ? lo1 + 1 : 63u; // the raw lane after it
-    const uint32_t hb1 = S.hbase[lo1], hbn = lo1 < 63 ? S.hbase[ln] : R, hbnn = lo1 < 62 ? S.hbase[lo1 + 2 > 63 ? 63 : lo1 + 2] : R;
-    // (mad24: as plain index arithmetic the row addresses and lane offsets became v_mad_u64_u32)
-    const uint32_t *fm0 = &S.fm[0][0];
-    const uint32_t *r1 = fm0 + mad24(lo1, 5u, 0u), *rn = fm0 + mad24(ln, 5u, 0u);
-    uint32_t w1[5], wn[5];
-#pragma unroll
-    for (int d = 0; d < 5; d++) {
-        w1[d] = r1[d];
-        wn[d] = rn[d];
-    }
-    const uint32_t n1 = x - hb1;
-    raw_x = mad24(lo1, (uint32_t)TILE_T, decode(w1, n1));
-    const uint32_t m2 = n1 + l; // head x + l, counted from the first head of lane lo1
-    const bool same = m2 < hbn - hb1, next = !same && m2 - (hbn - hb1) < hbnn - hbn;
-    uint32_t w2[5];
-#pragma unroll
-    for (int d = 0; d < 5; d++) w2[d] = same ? w1[d] : wn[d];
-    uint32_t re = mad24(same ? lo1 : ln, (uint32_t)TILE_T, decode(w2, same ? m2 : m2 - (hbn - hb1)));
-    if (y_in && !same && !next) { // the next lane holds fewer than l heads beyond x: search for head x + l like for head x
-        const uint32_t lo2 = owner(y);
-        const uint32_t *r3 = fm0 + mad24(lo2, 5u, 0u);
-        uint32_t w3[5];
-#pragma unroll
-        for (int d = 0; d < 5; d++) w3[d] = r3[d];
-        re = mad24(lo2, (uint32_t)TILE_T, decode(w3, y - S.hbase[lo2]));
-    }
-    const uint32_t hx = y - R; // only meaningful when !y_in; validated hits guarantee hx < halo_n
-    const uint32_t he = S.halo_pos[(!y_in && hx < halo_n) ? hx : 0];
-    raw_e = y_in ? re : he;
+    (void)rcpTq;
+    const BmFirst f = hpc_rawpos_first(S, x, l, R, halo_n);
+    hpc_rawpos_rest(S, f, raw_x, raw_e);
 }
-#endif
-#if S2K_BM2
+static_assert(TILE_T % (4 * ROW_W) == 0, "raw offset of a lane = its row offset times a whole number");
 // run heads of the tile before the raw byte at tile-relative offset rel (< TILE_BASES): prefix of its lane + heads of the lane's earlier
 // flag words + those of its own word below its bit -- two reads, one round trip
 template <class WL>
@@ -890,7 +807,6 @@ __device__ __forceinline__ uint32_t heads_before_raw(const WL &S, uint32_t rel) 
     const uint32_t wd = S.row[o][g];
     return (pc.x >> 16) + heads_before_word(pc.y, g) + __popc(wd & ((1u << (wi & 31u)) - 1u)); // (g = 4: wi & 31 < 16, the prefix bits are masked off)
 }
-#endif
 
 // HpcSimd without a second pass over the bases: run heads that the tiles before tile t hold of the read that continues into it.
 // Every tile publishes one word right after its compaction (publish_tile_heads): HW_VALID | count of its run heads that belong
@@ -944,20 +860,7 @@ __device__ __forceinline__ void publish_tile_heads(uint32_t *W, uint64_t t, cons
     } else if (last_start >= t0 + tile_len) {
         word = HW_VALID; // a read starts exactly where the tile ends: nothing continues past it
     } else { // run heads from the last read start on: nh - rank of that (forced) head
-#if S2K_BM2
         const uint32_t c = heads_before_raw(S, (uint32_t)(last_start - t0));
-#else
-        const uint32_t rel = (uint32_t)(last_start - t0), o = div_tile_t(rel), wi = rel - __umul24(o, (uint32_t)TILE_T);
-        uint32_t c = S.hbase[o];
-        uint32_t f[5];
-#pragma unroll
-        for (int gg = 0; gg < 5; gg++) f[gg] = S.fm[o][gg]; // (all five at once: one LDS round trip, not one per word)
-#pragma unroll
-        for (int gg = 0; gg < 5; gg++) {
-            const int v = (int)wi - 32 * gg; // bits of word gg that lie before the read start
-            c += __popc(f[gg] & (v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << v) - 1u))));
-        }
-#endif
         word = HW_VALID | (nh - c);
     }
     if (lane == 0) __hip_atomic_store(W + t, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1014,16 +917,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             if (internal || (external && lane == first_ext)) {
                 if constexpr (HPC) {
                     if (bpos < tile_end) { // rank of the forced run head at raw offset bpos - t0
-#if S2K_BM2
                         HB = (int32_t)heads_before_raw(S, (uint32_t)(bpos - t0)); // run heads before the forced one
-#else
-                        const uint32_t rel = (uint32_t)(bpos - t0), o = div_tile_t(rel), wi = rel - __umul24(o, (uint32_t)TILE_T);
-                        const uint32_t g = wi >> 5;
-                        uint32_t c = S.hbase[o];
-                        for (uint32_t gg = 0; gg < g; gg++) c += __popc(S.fm[o][gg]);
-                        c += __popc(S.fm[o][g] & ((1u << (wi & 31u)) - 1u)); // run heads before the forced one
-                        HB = (int32_t)c;
-#endif
                     } else { // first read start (or stream end) after the tile: count the run heads before it
                         HB = -1; // resolved below by the whole wave
                     }
@@ -1275,28 +1169,36 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             uint32_t f = 0, r = 0;
             if constexpr (L > 0) {
                 constexpr uint32_t PER = (L + 3) / 4;
+                // all of the lane's bytes first, then all of their table entries: two LDS round trips per pass (round 4: four -- groups of
+                // four bases with a scheduling barrier between them, from when the kept hashes and hit masks were still live here)
+                constexpr uint32_t GRP = S2K_REDERIVE_GROUP;
 #pragma unroll
-                for (uint32_t h0 = 0; h0 < PER; h0 += 4) { // groups of four bases: bounded register use
-                    uint32_t by[4];
-                    uint2 ti[4];
+                for (uint32_t h0 = 0; h0 < PER; h0 += GRP) {
+                    uint32_t by[GRP];
+                    uint2 ti[GRP];
 #pragma unroll
-                    for (uint32_t ii = 0; ii < 4; ii++)
+                    for (uint32_t ii = 0; ii < GRP; ii++)
                         if (h0 + ii < PER) by[ii] = q[h0 + ii];
 #pragma unroll
-                    for (uint32_t ii = 0; ii < 4; ii++)
+                    for (uint32_t ii = 0; ii < GRP; ii++)
                         if (h0 + ii < PER) ti[ii] = tab_in(tab, by[ii]); // IN pair = {h[c], rotl(rc[c], l-1)}
-                    uint32_t tf[4] = {0, 0, 0, 0}, tr[4] = {0, 0, 0, 0};
+                    uint32_t tf[GRP], tr[GRP];
 #pragma unroll
-                    for (uint32_t ii = 0; ii < 4; ii++)
+                    for (uint32_t ii = 0; ii < GRP; ii++) {
+                        tf[ii] = tr[ii] = 0u;
                         if (h0 + ii < PER) {
                             const uint32_t i = i0 + h0 + ii, rot = (uint32_t)L - 1u - i;
                             const bool valid = 3 * PER + h0 + ii < (uint32_t)L || i < (uint32_t)L; // only the last quarter can run past l
                             tf[ii] = valid ? rotl32(ti[ii].x, rot) : 0u;
                             tr[ii] = valid ? rotr32(ti[ii].y, rot) : 0u;
                         }
-                    f = xor3(xor3(f, tf[0], tf[1]), tf[2], tf[3]); // two terms per instruction (v_bitop3_b32)
-                    r = xor3(xor3(r, tr[0], tr[1]), tr[2], tr[3]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (uint32_t ii = 0; ii < GRP; ii += 4) {
+                        f = xor3(xor3(f, tf[ii], tf[ii + 1]), tf[ii + 2], tf[ii + 3]); // two terms per instruction (v_bitop3_b32)
+                        r = xor3(xor3(r, tr[ii], tr[ii + 1]), tr[ii + 2], tr[ii + 3]);
+                    }
+                    if (GRP < PER) __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 for (uint32_t ii = 0; ii < per; ii++) {
@@ -1409,9 +1311,9 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
             const uint32_t kk = k0 + lane;
             const bool act = kk < bn;
             uint32_t x = 0, rid = 0;
+            uint32_t prel = 0, erel = 0; // tile-relative: the l-mer's first base; the last base that belongs to it (may lie far behind the tile)
             if (act) x = S.list[kk] & 0x3FFFu;
             S2K_STAMP(8); // round: list read
-            uint32_t prel = 0, erel = 0; // tile-relative: the l-mer's first base; the last base that belongs to it (may lie far behind the tile)
             if (act) backmap(x, prel, erel);
             S2K_STAMP(9); // round: back-map
             if constexpr (DESC) {
@@ -1701,11 +1603,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
         if (lane == 0) S.buf[HS_OFF - 1] = 0;
         if constexpr (HPC) {
 #pragma unroll
-#if S2K_BM2
             for (int g2 = 0; g2 < 5; g2++) S.row[lane][g2] = 0; // read-start marks are OR-ed in by hpc_compact
-#else
-            for (int g2 = 0; g2 < 5; g2++) S.fm[lane][g2] = 0; // read-start marks are OR-ed in by hpc_compact
-#endif
         }
         wave_sync();
         S2K_STAMP(0); // staging
