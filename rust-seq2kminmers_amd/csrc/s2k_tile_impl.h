@@ -144,7 +144,15 @@ constexpr int SEED_TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c
 // select-nth-set-bit are one look-up
 constexpr int TABLE_BYTES = SEED_TABLE_BYTES; // (tools/experiments)
 constexpr int SEL8_OFF = SEED_TABLE_BYTES, SEL8_BYTES = S2K_SEL8 ? 256 * 8 : 0;
-template <bool HPC> constexpr int table_bytes() { return SEED_TABLE_BYTES + (HPC ? SEL8_BYTES : 0); }
+#ifndef S2K_PASS2_GROUP
+#define S2K_PASS2_GROUP 12
+#endif
+#ifndef S2K_PASS2_ACC
+#define S2K_PASS2_ACC 1 // Hpc compaction, pass 2: 1 = register accumulator + aligned ds_or_b32 (round 5), 0 = one byte store per raw byte (rounds 1-4)
+#endif
+// Hpc, behind sel8: pk4[n] = {v_perm_b32 selector that packs the bytes of a dword whose flag nibble is n to its low end, 8 x popcount(n)} (128 B)
+constexpr int PK4_OFF = SEL8_OFF + SEL8_BYTES, PK4_BYTES = S2K_PASS2_ACC ? 16 * 8 : 0;
+template <bool HPC> constexpr int table_bytes() { return SEED_TABLE_BYTES + (HPC ? SEL8_BYTES + PK4_BYTES : 0); }
 template <bool HPC>
 constexpr int block_lds_bytes() { return table_bytes<HPC>() + TW * (int)sizeof(WaveLdsT<HPC>) + PROFILE_LDS_BYTES; }
 // one block of TW = 12 waves per CU: it may use the whole 160 KiB (MI355X_MICROARCH.md: "a single workgroup may declare all 160 KiB")
@@ -643,6 +651,52 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     //    (Byte stores on purpose: a ds_write_b32 at an address that is not a multiple of 4 is executed one lane per cycle --
     //    64 cycles per wave instruction against ~4 for ds_write_b8, tools/experiments/lds_rate.hip -- so packing the heads
     //    of a dword with v_perm_b32 and storing them with one unaligned dword store was 2x slower than this.)
+#if S2K_PASS2_ACC
+    // 4. pass 2 (round 5): the run heads of a dword are packed to its low end by ONE v_perm_b32 (selector and count from the 16-entry table
+    //    pk4, indexed by the dword's flag nibble), merged into a 64-bit window at the lane's fill level, and the window's low dword is OR-ed
+    //    into the (zeroed) buffer at an ALIGNED address every step -- ds_or_b32: partial states of a dword are subsets of its final state,
+    //    so storing early and often is harmless, and the dwords two lanes share (a lane's run heads begin and end at any byte) merge by
+    //    themselves.  36 aligned LDS operations per lane instead of 144 byte stores whose data-dependent slots collided in the banks: a byte store
+    //    cost 5.5 units of a plain vector instruction's 1.0 where it ran (3.1 without the conflicts; profiles/r05_instruction_costs.txt).
+    {
+        typedef __attribute__((address_space(3))) const unsigned long long *lds_cu64;
+        uint4 *zp = reinterpret_cast<uint4 *>(D + lane_off);
+#pragma unroll
+        for (int p = 0; p < 9; p++) zp[p] = make_uint4(0, 0, 0, 0); // (every lane holds its raw chunk in registers)
+        asm volatile("" ::: "memory");
+        uint32_t waddr = (uint32_t)(uintptr_t)(lds_u8 *)D + (base & ~3u); // aligned LDS address of the dword being filled
+        uint32_t fill8 = 8u * (base & 3u), lo = 0;                        // bits of it that belong to the lanes before this one
+        constexpr int GRP2 = S2K_PASS2_GROUP; // table entries fetched at a time: one LDS round trip per group instead of one per dword
+#pragma unroll
+        for (int d0 = 0; d0 < 36; d0 += GRP2) {
+            unsigned long long e[GRP2];
+#pragma unroll
+            for (int dd = 0; dd < GRP2; dd++) {
+                const int d = d0 + dd, g = d >> 3, sft = 4 * (d & 7);
+                if (d < 36) {
+                    const uint32_t idx8 = sft >= 3 ? (fmk[g] >> (sft - 3)) & 0x78u : (fmk[g] << (3 - sft)) & 0x78u; // 8 x the dword's flag nibble
+                    e[dd] = *reinterpret_cast<lds_cu64>((uint32_t)PK4_OFF + idx8);
+                }
+            }
+#pragma unroll
+            for (int dd = 0; dd < GRP2; dd++) {
+                const int d = d0 + dd;
+                if (d < 36) {
+                    const uint32_t packed = __builtin_amdgcn_perm(0u, c[d], (uint32_t)e[dd]);
+                    const unsigned long long win = (unsigned long long)packed << fill8; // fill8 < 32
+                    lo |= (uint32_t)win;
+                    asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory");
+                    fill8 += (uint32_t)(e[dd] >> 32);
+                    const bool full = fill8 >= 32u;
+                    lo = full ? (uint32_t)(win >> 32) : lo;
+                    waddr += full ? 4u : 0u;
+                    fill8 &= 31u;
+                }
+            }
+        }
+        asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory"); // what a last completed dword left over
+    }
+#else
     {
         uint32_t gaddr = (uint32_t)(uintptr_t)(lds_u8 *)D + base - 1; // LDS byte address of slot -1
         auto pass2 = [&](auto partial_c) {
@@ -654,11 +708,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const int i = (4 * d + b) & 31;
-#ifdef S2K_X1 // (timing experiment only, WRONG results: every lane stores into its own bank -- what do the scatter's bank conflicts cost?)
-                    const uint32_t a = ((gaddr & ~0x7Cu) | (((uint32_t)lane & 31u) << 2)) + (__popc(fmk[g] & (i == 31 ? 0xFFFFFFFFu : ((2u << i) - 1u))) & 3u);
-#else
                     const uint32_t a = gaddr + __popc(fmk[g] & (i == 31 ? 0xFFFFFFFFu : ((2u << i) - 1u))); // v_and + v_bcnt(+gaddr)
-#endif
                     if (!PARTIAL || 4 * d + b < vb) {
                         if (b == 0) asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(c[d]) : "memory");
                         if (b == 1) asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(hi) : "memory");
@@ -673,6 +723,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         if (partial) pass2(std::true_type{});
         else pass2(std::false_type{});
     }
+#endif
     S2K_STAMP(15); // compaction: stores
     // 5. run heads that follow the tile: up to l of them (hash needs l-1, the end position one more); the HpcSimd
     //    tail rule looks 16 heads further for the end of the read
@@ -1412,6 +1463,15 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
             const uint32_t m = (uint32_t)c >> 3, n = (uint32_t)c & 7u;
             smem[SEL8_OFF + c] = (uint8_t)(n < (uint32_t)__popc(m) ? select_nth_32(m, n) : 0u);
         }
+    if constexpr (HPC && S2K_PASS2_ACC != 0)
+        if (threadIdx.x < 16) {
+            const uint32_t n = threadIdx.x;
+            uint32_t sel = 0, j = 0;
+            for (uint32_t b = 0; b < 4; b++)
+                if ((n >> b) & 1u) sel |= b << (8 * j++); // byte j of the result = byte b of the dword (v_perm_b32: 0..3 = bytes of the second source)
+            for (; j < 4; j++) sel |= 0x0Cu << (8 * j);   // ... 0x0C = the constant 0x00
+            reinterpret_cast<uint2 *>(smem + PK4_OFF)[n] = make_uint2(sel, 8u * (uint32_t)__popc(n));
+        }
     __syncthreads(); // the only workgroup barrier; waves are independent from here on
 #ifdef S2K_DEBUG_KNOBS
     const uint64_t dbg_mt0 = __builtin_amdgcn_s_memtime(), dbg_rt0 = __builtin_amdgcn_s_memrealtime();
@@ -1667,6 +1727,34 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
 #endif
             wave_sync();
             __builtin_amdgcn_sched_barrier(0);
+#ifdef S2K_XCAL // (calibration experiment, tools/ab: what does one more instruction of a kind cost the tile?  256 of them per tile, results unchanged)
+            {
+                uint32_t dv = (uint32_t)lane, dv2 = (uint32_t)lane + 3u, ds = (uint32_t)t;
+                (void)dv; (void)dv2; (void)ds;
+#pragma unroll
+                for (int i_ = 0; i_ < 64; i_++) {
+#if S2K_XCAL == 1
+                    asm volatile("v_xor_b32 %0, %0, %1\n\tv_xor_b32 %1, %1, %0\n\tv_xor_b32 %0, %0, %1\n\tv_xor_b32 %1, %1, %0" : "+v"(dv), "+v"(dv2));
+#elif S2K_XCAL == 2
+                    asm volatile("v_alignbit_b32 %0, %0, %1, 7\n\tv_alignbit_b32 %1, %1, %0, 9\n\tv_alignbit_b32 %0, %0, %1, 7\n\tv_alignbit_b32 %1, %1, %0, 9" : "+v"(dv), "+v"(dv2));
+#elif S2K_XCAL == 3
+                    asm volatile("s_add_u32 %0, %0, 1\n\ts_xor_b32 %0, %0, 5\n\ts_add_u32 %0, %0, 3\n\ts_xor_b32 %0, %0, 9" : "+s"(ds));
+#elif S2K_XCAL == 4
+                    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\tds_read_b32 %0, %2 offset:8\n\tds_read_b32 %1, %2 offset:12" : "=v"(dv), "=v"(dv2) : "v"(4u * (uint32_t)lane) : "memory");
+#elif S2K_XCAL == 6 /* 64 reads, 4-way bank conflict each (lanes 8 apart share a bank): 8 LDS cycles instead of 2 */
+                    if (i_ < 16) asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\tds_read_b32 %0, %2 offset:8\n\tds_read_b32 %1, %2 offset:12" : "=v"(dv), "=v"(dv2) : "v"(4u * ((uint32_t)lane & 7u) + 128u * ((uint32_t)lane >> 3)) : "memory");
+#elif S2K_XCAL == 7 /* 64 reads, conflict-free */
+                    if (i_ < 16) asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\tds_read_b32 %0, %2 offset:8\n\tds_read_b32 %1, %2 offset:12" : "=v"(dv), "=v"(dv2) : "v"(4u * (uint32_t)lane) : "memory");
+#elif S2K_XCAL == 8 /* 64 reads, 16-way bank conflict each: 32 LDS cycles */
+                    if (i_ < 16) asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\tds_read_b32 %0, %2 offset:8\n\tds_read_b32 %1, %2 offset:12" : "=v"(dv), "=v"(dv2) : "v"(4u * ((uint32_t)lane & 1u) + 128u * ((uint32_t)lane >> 1)) : "memory");
+#elif S2K_XCAL == 5
+                    asm volatile("v_min_u32 %0, %0, %1\n\tv_max_u32 %1, %1, %0\n\tv_min_u32 %0, %0, %1\n\tv_max_u32 %1, %1, %0" : "+v"(dv), "+v"(dv2));
+#endif
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" ::"v"(dv), "v"(dv2), "s"(ds));
+            }
+#endif
             S2K_STAMP(2); // hash loop
         }
         // the draw made at the top of the iteration is looked at HERE: everything older than it in the vector-memory queue had
