@@ -138,6 +138,59 @@ def usable_cpus():
     return n
 
 
+class SensorSampler:
+    """Shader clock and package power of one GPU during a timed region, from the amdgpu hwmon files (freq1_input in Hz, power1_input in uW):
+    a thread that reads them every 10 ms.  The kernels of this path sustain ~2.0 GHz where the card idles at 2.4: the line says which it was."""
+
+    def __init__(self, props):
+        import glob
+
+        self.freq = self.power = None
+        want = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
+        for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                if want not in os.path.realpath(d):
+                    continue
+                for h in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+                    f, pw = os.path.join(h, "freq1_input"), os.path.join(h, "power1_input")
+                    if os.path.exists(f):
+                        self.freq, self.power = f, (pw if os.path.exists(pw) else None)
+            except OSError:
+                continue
+        self.mhz, self.watts, self._stop, self._thr = [], [], False, None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                self.mhz.append(int(open(self.freq).read()) / 1e6)
+                if self.power:
+                    self.watts.append(int(open(self.power).read()) / 1e6)
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.01)
+
+    def start(self):
+        if self.freq:
+            import threading
+
+            self.mhz, self.watts, self._stop = [], [], False
+            self._thr = threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+
+    def stop(self):
+        if self._thr:
+            self._stop = True
+            self._thr.join()
+            self._thr = None
+        m = sorted(x for x in self.mhz if x > 0)
+        if not m:
+            return None
+        out = {"sclk_mhz_median": round(m[len(m) // 2]), "sclk_mhz_min": round(m[0]), "sclk_mhz_max": round(m[-1]), "samples": len(m)}
+        if self.watts:
+            out["power_w_mean"] = round(sum(self.watts) / len(self.watts))
+        return out
+
+
 def kernel_source_id():
     """sha256 over the device sources of the library (csrc/*.hip, *.h, Makefile): what a committed PMC measurement belongs to"""
     import glob
@@ -358,6 +411,8 @@ def main():
                       "kernels_ms_per_step_max": round(float(t[2].item()), 3), "kernels_ms_per_step_min": round(-float(t[3].item()), 3)}
         return dt, counts, k_ms / steps, km_ms / steps, all_ms / steps, spread
 
+    sensors = SensorSampler(torch.cuda.get_device_properties(dev))
+    sensors.start()  # shader clock and power during the headline's timed regions (one context, then two)
     dt, counts, min_ms, km_ms, pipe_ms, rank_spread = timed(mode, args.steps, args.warmup)
     assert counts["path"] == (2 if args.legacy_path else 0), "the tiled HIP kernels (descriptor path unless --legacy-path) must be the ones measured"
     # ---- the same K steps, alternating between two contexts: what a loop over many batches gets (double buffering) -------------
@@ -420,6 +475,7 @@ def main():
             torch.cuda.empty_cache()
         if two_ctx is not None:
             dt = two_ctx
+    clocks = sensors.stop()
     # ---- verification outside the timed region: a read sample against the oracle ------------------
     verified = None
     if rank == 0 and args.verify_reads > 0:
@@ -454,7 +510,7 @@ def main():
                             and (outs["end"][g].cpu().numpy().view(np.uint32) == ref["end"]).all()
                             and (outs["rev"][g].cpu().numpy() == ref["rev"]).all())
         assert verified, "GPU output differs from the oracle on the verification sample"
-        verified = {"ok": True, "reads": int(len(ids)), "kminmers": int(ref["n"]), "sample": "reads drawn across the whole stream (rng 12345) + first/last"}
+        verified = {"ok": True, "reads": int(len(ids)), "kminmers": int(ref["n"])}
     if args.dump_shard:  # tests: concatenating the ranks' dumps must reproduce the unsharded run
         nk = counts["n_kminmers"]
         np.savez(args.dump_shard + ".rank%d.npz" % rank, km_off=outs["km_off"].cpu().numpy().view(np.uint64),
@@ -479,9 +535,8 @@ def main():
             dt3, counts3, _, _, pipe_ms3, _ = timed(hm, s3, 1, strict=False)
             assert counts3["path"] == (2 if args.legacy_path else 0)
             tot3 = sharding.allreduce_counts(counts3, dist, red_dev)
-            compat[nm] = {"value": round(tot3["n_bases"] * s3 / dt3 / 1e9, 2), "unit": "Gbp/s", "pipeline_ms": round(pipe_ms3, 3), "kminmers": int(tot3["n_kminmers"]),
-                          "calls_run_again": int(timed.reruns)}
-        other_line["compat_modes"] = compat
+            compat[nm] = {"value": round(tot3["n_bases"] * s3 / dt3 / 1e9, 1), "pipeline_ms": round(pipe_ms3, 3), "reruns": int(timed.reruns)}
+        other_line.update(compat)
 
     # ---- rates the headline does not show, N = 1, outside the timed region: the other BASELINE configs that fit one GPU and the
     #      "next" rows of SURVEY.md 8f (standalone HPC = src/hpc.rs, README.md:23 "HPC alone"; minimizer triples = the iterators of
@@ -504,10 +559,9 @@ def main():
             all_ms, n_ev = eng.timing_total(0)
             k_ms, _ = eng.timing_total(1)
             eng.enable_timing(False)
-            return {"value": round(nb * steps / dtx / 1e9, 2), "unit": "Gbp/s", "ms_per_step": round(dtx / steps * 1e3, 3), "pipeline_ms": round(all_ms / steps, 3),
-                    "kernel_ms": round(k_ms / steps, 3), "bases": int(nb), "reads": int(nr), "minimizers": c["n_minimizers"], "kminmers": c["n_kminmers"],
-                    "roofline_frac": round((nb + 17 * c["n_kminmers"] + 16 * (nr + 1)) / (all_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "calls_run_again": int(n_ev - steps)}
+            return {"value": round(nb * steps / dtx / 1e9, 1), "pipeline_ms": round(all_ms / steps, 3), "kminmers": c["n_kminmers"],
+                    "frac": round((nb + 17 * c["n_kminmers"] + 16 * (nr + 1)) / (all_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                    "reruns": int(n_ev - steps)}
 
         def out_for(nr, cap):
             t = {"km_off": torch.empty(nr + 1, dtype=torch.int64, device=dev), "hash": torch.empty(cap, dtype=torch.int64, device=dev),
@@ -529,8 +583,7 @@ def main():
         d_b3 = torch.empty(nb3 + 256, dtype=torch.uint8, device=dev)
         eng.synth_hifi_device(3, 0, nr3, d_o3.data_ptr(), d_b3.data_ptr())
         t3, o3 = out_for(nr3, int(nb3 * 0.0135) + 1_000_000)
-        c3 = {"name": "BASELINE configs[3]", "workload": "%d HiFi-like reads (%.1f Gbp): lengths ~N(15k, 2k), geometric homopolymer runs of mean 2, ~0.1%% of the runs 20..2999 bases; d=%g" % (
-            nr3, nb3 / 1e9, args.density)}
+        c3 = {"config": 3, "gbp": round(nb3 / 1e9, 2)}  # (README.md, 'Reading the bench line': what the workloads are)
         for nm, hm in (("hpc", pkg.HashMode.Hpc), ("hpcsimd", pkg.HashMode.HpcSimd), ("regular", pkg.HashMode.Regular)):
             c3[nm] = rate(d_b3, d_o3, nr3, nb3, hm, args.density, o3)
         other_configs["hifi"] = c3
@@ -541,7 +594,7 @@ def main():
         d_b4 = torch.empty(nr4 * rl4 + 256, dtype=torch.uint8, device=dev)
         eng.synth_bases_device(4, 0, nr4 * rl4, d_b4.data_ptr())
         t4, o4 = out_for(nr4, int(nr4 * rl4 * 0.0026) + 1_000_000)
-        c4 = {"name": "BASELINE configs[4]", "workload": "%d x %d bp uniform-random contigs (%.1f Gbp), d=0.001" % (nr4, rl4, nr4 * rl4 / 1e9)}
+        c4 = {"config": 4, "gbp": round(nr4 * rl4 / 1e9, 2)}
         for nm, hm in (("hpc", pkg.HashMode.Hpc), ("regular", pkg.HashMode.Regular)):
             c4[nm] = rate(d_b4, d_o4, nr4, nr4 * rl4, hm, 0.001, o4)
         other_configs["contigs"] = c4
@@ -554,10 +607,9 @@ def main():
               "mn_jend": torch.empty(mcap, dtype=torch.int32, device=dev), "mn_hash": torch.empty(mcap, dtype=torch.int32, device=dev)}
         o.mn_capacity = mcap
         o.mn_off, o.mn_j, o.mn_jend, o.mn_hash = (tm[x].data_ptr() for x in ("mn_off", "mn_j", "mn_jend", "mn_hash"))
-        minimizers_only = {"what": "s2k_extract_device with S2K_FLAG_WANT_MINIMIZERS on the headline workload: k-min-mers AND the minimizer triples "
-                                   "(start, end, hash32) of the iterators of src/nthash_hpc.rs:193 / src/nthash_avx512_32.rs:14 (+12 B per minimizer written)"}
+        minimizers_only = {}
         for nm, hm in ((args.mode, mode), ("regular" if args.mode == "hpc" else "hpc", other)):
-            minimizers_only[nm] = rate(d_bases, d_off, n_reads, n_bases, hm, args.density, o, flags=pkg.FLAG_WANT_MINIMIZERS)
+            minimizers_only[nm] = rate(d_bases, d_off, n_reads, n_bases, hm, args.density, o, flags=pkg.FLAG_WANT_MINIMIZERS)["value"]
         o.mn_capacity = 0
         o.mn_off = o.mn_j = o.mn_jend = o.mn_hash = None
         del tm
@@ -568,11 +620,8 @@ def main():
         hcap = int(nbh * 0.80) + 4096
         th = {"off": torch.empty(nrh + 1, dtype=torch.int64, device=dev), "hpc": torch.empty(hcap, dtype=torch.uint8, device=dev),
               "pos": torch.empty(hcap, dtype=torch.int32, device=dev)}
-        standalone_hpc = {"what": "s2k_hpc_device(_ex) on the first %d reads (%.1f Gbp): compressed string + read-relative run starts per read, resident in HBM; "
-                                  "best of 3 wall-clock calls; the reference's comparator is README.md:23 'HPC alone ~4 GB/s' (AVX-512, one thread)" % (nrh, nbh / 1e9),
-                          "unit": "Gbp/s"}
-        for nm, rle in (("hpc / encode_rle_simd (any repeated byte collapses, src/hpc.rs:28-41,44-147)", False),
-                        ("encode_rle (only ACTGactgNn collapse, src/hpc.rs:7-25)", True)):
+        standalone_hpc = {"unit": "Gbp/s", "gbp": round(nbh / 1e9, 2)}
+        for nm, rle in (("hpc", False), ("encode_rle", True)):  # src/hpc.rs:28-41,44-147 (any repeated byte collapses) / :7-25 (only ACTGactgNn)
             best, runs = None, 0
             for _ in range(4):
                 torch.cuda.synchronize(dev)
@@ -581,8 +630,8 @@ def main():
                 torch.cuda.synchronize(dev)
                 dth = time.perf_counter() - t0
                 best = dth if best is None else min(best, dth)
-            standalone_hpc[nm] = {"value": round(nbh / best / 1e9, 1), "ms": round(best * 1e3, 3), "runs": int(runs),
-                                  "algorithmic_gb_s": round((nbh + 5 * runs + 8 * (nrh + 1)) / best / 1e9, 1)}
+            standalone_hpc[nm] = round(nbh / best / 1e9, 1)
+            standalone_hpc[nm + "_gb_s"] = round((nbh + 5 * runs + 8 * (nrh + 1)) / best / 1e9, 1)  # algorithmic bytes: 1 read + 5 written per run
         del th
         torch.cuda.empty_cache()
 
@@ -631,7 +680,7 @@ def main():
     achieved = alg_bytes / (pipe_ms * 1e-3) / 1e9
     # the dominant kernel on its own: it reads the bases and the read table once and writes 8 B per minimizer record (16 B on the legacy path)
     kern_bytes = counts["n_bases"] + (16 if args.legacy_path else 8) * counts["n_minimizers"] + 8 * (n_reads + 1)
-    traffic, traffic_src, traffic_stale = None, None, None
+    traffic, traffic_stale, issue = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath) and args.workload == "c2":
         try:
@@ -639,25 +688,28 @@ def main():
             if tj.get("mode") == args.mode and tj.get("n_bases") == n_bases:
                 # the PMC passes belong to ONE state of the kernels: the file carries the id of the sources it was measured on
                 if tj.get("kernel_source_id") == kernel_source_id():
-                    traffic, traffic_src = tj.get("hbm_bytes_per_step"), tj.get("source")
+                    traffic = tj.get("hbm_bytes_per_step")
+                    sq = tj.get("sq_per_step")
+                    if sq:
+                        # the limiter as a number: vector instructions issued per step against what the SIMDs could issue in the step's time at one
+                        # wave64 instruction per 2 cycles (SIMD-32, MI355X_MICROARCH.md) and the shader clock sampled during THIS run
+                        mhz = (clocks or {}).get("sclk_mhz_median") or tj.get("shader_mhz") or 2400
+                        n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+                        issue = {"valu_insts_per_step": int(sq["SQ_INSTS_VALU"]), "all_insts_per_step": int(sq["all_insts"]), "shader_mhz": mhz,
+                                 "frac_of_2cycle_issue": round(sq["SQ_INSTS_VALU"] * 2.0 / (n_simd * pipe_ms * 1e-3 * mhz * 1e6), 3),
+                                 "lds_conflict_frac": round(sq["SQ_LDS_BANK_CONFLICT"] / max(sq["SQ_LDS_IDX_ACTIVE"], 1.0), 3)}
                 else:
-                    traffic_stale = {"measured_on": tj.get("kernel_source_id"), "sources_now": kernel_source_id(), "stale_value": tj.get("hbm_bytes_per_step"),
-                                     "how_to_refresh": "tools/profile.sh on the GPU box, then commit profiles/traffic_latest.json"}
+                    traffic_stale = {"measured_on": tj.get("kernel_source_id"), "now": kernel_source_id(), "stale_value": tj.get("hbm_bytes_per_step")}
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
                 "algorithmic_bytes_per_step": int(alg_bytes), "bytes_per_base": round(alg_bytes / max(n_bases, 1), 4),
-                "time_ms": round(pipe_ms, 3), "time": "HIP events around all kernels of a step (s2k_timing_total(0)), averaged over the timed steps of the "
-                                                      "one-context run (with two contexts the calls overlap: a call's events would include the other's kernels)",
-                "frac_at_value": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                "time_ms": round(pipe_ms, 3), "frac_at_value": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                 "kernel": "tile_minimizer_kernel<%d,%s>" % (args.l, "hpc" if mode == pkg.HashMode.Hpc else "regular"),
                 "kernel_ms": round(min_ms, 3), "kernel_bytes": int(kern_bytes),
                 "kernel_frac": round(kern_bytes / (min_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kminmer_kernel_ms": round(km_ms, 3),
-                "kminmer_exposed_ms": round(max(pipe_ms - min_ms, 0.0), 3),
-                "overlap": None if args.legacy_path else "the call is cut into chunks of tiles; scan + k-min-mer kernel of chunk c run on a second stream beside the "
-                           "minimizer kernel of chunk c+1: kernel_ms and kminmer_kernel_ms are first-start-to-last-end spans that overlap, kminmer_exposed_ms = time_ms - kernel_ms",
-                "limiter": "integer VALU issue, not HBM: see DESIGN.md 3.1 and tools/experiments/valu_rate.hip"}
+                "kminmer_exposed_ms": round(max(pipe_ms - min_ms, 0.0), 3)}
 
     # ---- PCIe-inclusive legs (SURVEY 8d "what is timed (2)"): never `value`, reported beside it; N = 1, outside the timed region -----
     e2e = None
@@ -684,9 +736,7 @@ def main():
         for m, name in ((mode, args.mode), (other, "regular" if args.mode == "hpc" else "hpc")):
             c_extract(m)  # warm-up: pinned rings, result pool
             dt_e, nk_e = min(c_extract(m) for _ in range(3))
-            legs[name] = {"gbp_s": round(ne * rl / dt_e / 1e9, 2), "ms": round(dt_e * 1e3, 2), "kminmers": nk_e,
-                          "bytes_over_link": {"h2d": int(ne * rl // 4 + 8 * (ne + 1)), "d2h": int(17 * nk_e + 8 * (ne + 1)),
-                                              "note": "bases travel 2-bit packed (4 per byte; every byte that is not A/C/G/T in an exception list), results as SoA"}}
+            legs[name] = {"gbp_s": round(ne * rl / dt_e / 1e9, 1), "h2d": int(ne * rl // 4 + 8 * (ne + 1)), "d2h": int(17 * nk_e + 8 * (ne + 1))}
         file_leg = None
         try:
             path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "s2k_bench_%d.fa" % os.getpid())
@@ -698,15 +748,12 @@ def main():
             fbytes = os.path.getsize(path)
             eng.run_file(path, args.l, args.k, args.density, mode)  # warm-up: page cache settles
             best = min((eng.run_file(path, args.l, args.k, args.density, mode) for _ in range(2)), key=lambda r: r["seconds"])
-            file_leg = {"gbp_s": round(best["n_bases"] / best["seconds"] / 1e9, 2), "ms": round(best["seconds"] * 1e3, 2), "file_bytes": int(fbytes),
-                        "what": "s2k_run_file on a FASTA of the same reads in the page cache: read, staged 2-bit packed, split into records on the GPU, "
-                                "k-min-mers counted as in src/main.rs:65-81 (wall clock of the whole call)"}
+            file_leg = round(best["n_bases"] / best["seconds"] / 1e9, 1)
             os.remove(path)
         except OSError as ex:  # no room for the file: the leg is skipped, the bench line stands
             file_leg = "n/a (%s)" % type(ex).__name__
-        e2e = {"what": "s2k_extract: %d reads x %d bp (%.1f Gbp) in pageable host memory -> k-min-mers in host SoA, best of 3 after a warm-up" % (ne, rl, ne * rl / 1e9),
-               "gbp_s": legs[args.mode]["gbp_s"], "bytes_over_link": legs[args.mode]["bytes_over_link"], "host_cpus": usable_cpus(),
-               "modes": legs, "run_file": file_leg}
+        e2e = {"gbp": round(ne * rl / 1e9, 2), "extract_gbp_s": legs[args.mode]["gbp_s"], "extract_other_mode_gbp_s": legs["regular" if args.mode == "hpc" else "hpc"]["gbp_s"],
+               "h2d_bytes": legs[args.mode]["h2d"], "d2h_bytes": legs[args.mode]["d2h"], "run_file_gbp_s": file_leg, "host_cpus": usable_cpus()}
         del hb
 
     # ---- CPU baseline: the oracle = scalar port of the reference, on this host's cores --------------
@@ -732,30 +779,30 @@ def main():
         n2, r2, reps2 = clocked(lambda th, rp: orc.batch_count_clocked(hb, hoff, args.l, args.k, args.density, omode, threads=th, repeats=rp),
                                 ncpu, 3.0, r1 * 1e9)
         assert n1 == n2
-        # the reference's own fast path is AVX-512 (HashMode::Simd / HpcSimd): time a restatement of it too, if the host can
-        avx = None
+        # the reference's own fast path is AVX-512 (HashMode::Simd / HpcSimd): two restatements of it, if the host can -- "doubling" (a log-step
+        # scan of our own, round 2) and "reference_shape" (the reference's 16-lane rolling scan with the lane-15 carry and compress-stores,
+        # src/nthash_avx512_32.rs:117-151,367-420, src/hpc.rs:74-115); README.md, 'Reading the bench line'
+        avx = {}
         try:
             av = so.OracleAvx512()
             if av.supported():
                 hp = 1 if mode == pkg.HashMode.Hpc else 0
-                a1, ra1, _ = clocked(lambda th, rp: av.batch_count_clocked(hb, hoff, args.l, args.k, args.density, hp, threads=th, repeats=rp), 1, 0)
-                a2, ra2, repsa = clocked(lambda th, rp: av.batch_count_clocked(hb, hoff, args.l, args.k, args.density, hp, threads=th, repeats=rp),
-                                         ncpu, 3.0, ra1 * 1e9)
-                assert a1 == a2
-                avx = {"mode": "HpcSimd" if hp else "Simd", "value": round(ra1, 4), "cores": 1,
-                       "all_cores": {"value": round(ra2, 4), "threads": ncpu, "passes": repsa},
-                       "note": "oracle/s2k_oracle_avx512.c: restatement of the Simd-mode semantics (strict <, f32 bound), not the reference's code"}
+                for key, variant in (("avx512", 0), ("avx512_reference_shape", 1)):
+                    if variant and not av.has_reference_shape():
+                        continue
+                    fn = lambda th, rp, v=variant: av.batch_count_clocked(hb, hoff, args.l, args.k, args.density, hp, threads=th, repeats=rp, variant=v)  # noqa: E731
+                    a1, ra1, _ = clocked(fn, 1, 0)
+                    a2, ra2, _ = clocked(fn, ncpu, 3.0, ra1 * 1e9)
+                    assert a1 == a2
+                    avx[key] = {"mode": "HpcSimd" if hp else "Simd", "value": round(ra1, 3), "cores": 1, "all_cores": round(ra2, 2), "threads": ncpu}
             else:
-                avx = "n/a (host CPU lacks AVX-512 F/BW/VL/VBMI2)"
+                avx["avx512"] = "n/a (no AVX-512 F/BW/VL/VBMI2)"
         except Exception as e:  # the baseline must never break the bench line
-            avx = "n/a (%s)" % type(e).__name__
+            avx.setdefault("avx512", "n/a (%s)" % type(e).__name__)
         cpu = {"value": round(r1, 4), "unit": "Gbp/s", "cores": 1, "kind": "port",
-               "sample": "first %d reads (%.2f Gbp) of the same synthetic workload, count-only iteration as in src/main.rs:65-76, "
-                         "oracle/s2k_oracle.c built -O3 -march=native; threads created and warmed before the clock starts" % (ns, sample / 1e9),
-               "all_cores": {"value": round(r2, 4), "threads": ncpu, "passes": reps2,
-                             "host": "%d CPUs usable by this process (affinity / cgroup quota) of %d hardware threads, %s physical cores" % (ncpu, nhw, nphys)},
-               "avx512": avx,
-               "reference_published": "README.md:23: scalar ~0.1-0.2 GB/s, AVX-512 ~1 GB/s per thread (ntHash only, unstated CPU)"}
+               "sample": "first %d reads (%.2f Gbp) of the workload, count-only" % (ns, sample / 1e9),
+               "all_cores": round(r2, 3), "threads": ncpu, "host_threads": nhw, "host_cores": nphys}
+        cpu.update(avx)
 
     if rank == 0:
         value = tot_bases * args.steps / dt / 1e9
@@ -765,11 +812,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "contexts": 2 if two_ctx is not None else 1,
-            "one_context": {"value": round(tot_bases * args.steps / dt_one / 1e9, 2), "ms_per_step": round(dt_one / args.steps * 1e3, 3),
-                            "what": "the same K steps through ONE context: every call waits for the one before it (the host looks at a call's counts before it "
-                                    "enqueues the next).  'value' alternates the steps between two contexts -- two caller streams, two sets of output arrays, "
-                                    "the same input -- so that the tail of a call runs beside the first chunk of the next; roofline.* and per_rank are taken "
-                                    "from this one-context run (kernel times unperturbed)"},
+            "one_context": {"value": round(tot_bases * args.steps / dt_one / 1e9, 2), "ms_per_step": round(dt_one / args.steps * 1e3, 3)},
             "config": dict({"workload": "%s, HashMode::%s, l=%d k=%d d=%g; inputs resident in HBM" % (
                 wl_text, "Hpc" if mode == pkg.HashMode.Hpc else "Regular", args.l, args.k, args.density),
                 "name": {"c2": "BASELINE configs[1]", "ont": "BASELINE configs[2]", "hifi": "BASELINE configs[3]"}[args.workload], "mode": args.mode,
@@ -777,11 +820,13 @@ def main():
             "counts": {"bases": tot_bases, "minimizers": tot_min, "kminmers": tot_km, "xor_hash_rank0": counts["xor_hash"]},
             "verified_vs_oracle": verified,
             "other_mode": other_line, "other_configs": other_configs, "standalone_hpc": standalone_hpc, "minimizers_only": minimizers_only,
-            "downstream_count": count_line, "collective": collective, "per_rank": rank_spread,
-            "end_to_end": e2e,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "end_to_end": e2e, "downstream_count": count_line, "collective": collective, "per_rank": rank_spread,
+            "roofline": roofline, "issue": issue, "clocks": clocks, "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        line = {k: v for k, v in line.items() if v is not None or k in ("vs_baseline",)}  # (absent legs leave no key behind)
+        out = json.dumps(line, separators=(",", ":"))
+        assert len(out) <= 4096 or world > 1 or args.workload != "c2", "the bench line outgrew 4 KB (%d): the driver keeps its tail only" % len(out)
+        print(out, flush=True)
     if dist is not None:
         barrier()
         try:

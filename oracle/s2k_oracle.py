@@ -321,31 +321,39 @@ class OracleAvx512:
     def supported(self):
         return bool(self.lib.s2k_avx512_supported())
 
-    def minimizers(self, seq, l, bound, hpc):
+    def has_reference_shape(self):
+        """variant=1: the reference's own algorithm shape (16-lane rolling scan with the lane-15 carry, compress-stores, 16-base HPC steps)"""
+        return hasattr(self.lib, "s2k_avx512_minimizers_v")
+
+    def minimizers(self, seq, l, bound, hpc, variant=0):
         s = Oracle._seq(seq)
-        n = self.lib.s2k_avx512_minimizers(_ptr(s, _u8p), len(s), l, bound, int(hpc), None, None, None, 0)
+        fn = self.lib.s2k_avx512_minimizers_v
+        fn.restype = C.c_size_t
+        fn.argtypes = [_u8p, C.c_size_t, C.c_uint, C.c_uint32, C.c_int, _u32p, _u32p, _u32p, C.c_size_t, C.c_int]
+        n = fn(_ptr(s, _u8p), len(s), l, bound, int(hpc), None, None, None, 0, int(variant))
         j = np.empty(n, dtype=np.uint32)
         je = np.empty(n, dtype=np.uint32)
         h = np.empty(n, dtype=np.uint32)
-        self.lib.s2k_avx512_minimizers(_ptr(s, _u8p), len(s), l, bound, int(hpc), _ptr(j, _u32p), _ptr(je, _u32p), _ptr(h, _u32p), n)
+        fn(_ptr(s, _u8p), len(s), l, bound, int(hpc), _ptr(j, _u32p), _ptr(je, _u32p), _ptr(h, _u32p), n, int(variant))
         return j, je, h
 
-    def batch_count(self, bases, off, l, k, density, hpc, threads=1):
+    def batch_count(self, bases, off, l, k, density, hpc, threads=1, variant=0):
         """total k-min-mers, count-only (src/main.rs:65-76 with HashMode::Simd/HpcSimd); pthreads over read shards"""
         bases = Oracle._seq(bases)
         off = np.ascontiguousarray(off, dtype=np.uint64)
-        return int(self.lib.s2k_avx512_batch_count_mt(_ptr(bases, _u8p), _ptr(off, _u64p), len(off) - 1, l, k, density, int(hpc),
-                                                      int(threads)))
+        fn = self.lib.s2k_avx512_batch_count_mt_v
+        fn.restype = C.c_uint64
+        fn.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_double, C.c_int, C.c_int, C.c_int]
+        return int(fn(_ptr(bases, _u8p), _ptr(off, _u64p), len(off) - 1, l, k, density, int(hpc), int(threads), int(variant)))
 
-
-    def batch_count_clocked(self, bases, off, l, k, density, hpc, threads=1, repeats=1):
+    def batch_count_clocked(self, bases, off, l, k, density, hpc, threads=1, repeats=1, variant=0):
         bases = Oracle._seq(bases)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         sec = C.c_double(0.0)
-        fn = self.lib.s2k_avx512_batch_count_timed
+        fn = self.lib.s2k_avx512_batch_count_timed_v
         fn.restype = C.c_uint64
-        fn.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
-        n = fn(_ptr(bases, _u8p), _ptr(off, _u64p), len(off) - 1, l, k, density, int(hpc), int(threads), int(repeats), C.byref(sec))
+        fn.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
+        n = fn(_ptr(bases, _u8p), _ptr(off, _u64p), len(off) - 1, l, k, density, int(hpc), int(threads), int(repeats), C.byref(sec), int(variant))
         return int(n), float(sec.value)
 
 

@@ -35,10 +35,11 @@ def test_avx512_matches_scalar_simd_semantics(avx, oracle, ecoli):
             for d in (0.01, 0.3, 1.0):
                 b = oracle.hash_bound(d)
                 for hpc, mode in ((0, so.SIMD), (1, so.HPCSIMD)):
-                    j, je, h = avx.minimizers(s, l, b, hpc)
                     rj, rje, rh = oracle.minimizers(s, l, b, mode)
-                    assert len(j) == len(rj), (len(s), l, d, hpc)
-                    assert (j == rj).all() and (je == rje).all() and (h == rh).all(), (len(s), l, d, hpc)
+                    for variant in (0, 1):  # the doubling scan; the reference's rolling 16-lane scan (same results, two algorithms)
+                        j, je, h = avx.minimizers(s, l, b, hpc, variant=variant)
+                        assert len(j) == len(rj), (len(s), l, d, hpc, variant)
+                        assert (j == rj).all() and (je == rje).all() and (h == rh).all(), (len(s), l, d, hpc, variant)
 
 
 def test_avx512_batch_count(avx, oracle):
@@ -49,5 +50,6 @@ def test_avx512_batch_count(avx, oracle):
     bases = np.frombuffer(b"".join(reads), dtype=np.uint8)
     for hpc, mode in ((0, so.SIMD), (1, so.HPCSIMD)):
         ref = oracle.batch(bases, off, 31, 3, 0.05, mode, count_only=True)["n"]
-        assert avx.batch_count(bases, off, 31, 3, 0.05, hpc) == ref
-        assert avx.batch_count(bases, off, 31, 3, 0.05, hpc, threads=4) == ref
+        for variant in (0, 1):
+            assert avx.batch_count(bases, off, 31, 3, 0.05, hpc, variant=variant) == ref
+            assert avx.batch_count(bases, off, 31, 3, 0.05, hpc, threads=4, variant=variant) == ref

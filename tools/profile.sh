@@ -17,6 +17,8 @@ for mode in hpc regular; do
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/$mode/pmc/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 $args > $out/$mode.pmc_p$i.log 2>&1 || echo "pmc pass $i failed ($mode)"
   done
 done
+# the headline configuration itself (two chained contexts): kernel stats + trace, so that chunks x kernel time <= ms_per_step can be checked for `value`
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/hpc2ctx/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --mode hpc --contexts 2 --no-other-mode --no-cpu-baseline --no-end-to-end --verify-reads 0 > $out/hpc2ctx.stats.log 2>&1 || echo "stats pass failed (two contexts)"
 python3 - <<PY
 import csv, glob, json, collections, os
 out = "$out"
@@ -41,6 +43,7 @@ for mode in ("hpc", "regular"):
             agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines = []
     fetch = write = 0.0
+    sq = {}
     per_kernel = {}
     for k in sorted(agg):
         vals = {c: sum(v) / len(v) for c, v in agg[k].items()}
@@ -52,15 +55,33 @@ for mode in ("hpc", "regular"):
                          "hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024)}
         if "synth_kernel" in k or "at::native" in k or "elementwise_kernel" in k: continue  # run once per process, not per step
         fetch += f_kb * calls_per_step; write += w_kb * calls_per_step
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+            sq[c] = sq.get(c, 0.0) + vals.get(c, 0.0) * calls_per_step
     open(out + "/%s_pmc_summary.txt" % mode, "w").write("\n".join(lines) + "\n")
     import sys
     sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
     import bench  # kernel_source_id(): the state of the device sources these counters were collected on (bench.py refuses a stale file)
     res[mode] = {"mode": mode, "n_bases": 10000000000, "kernel_source_id": bench.kernel_source_id(), "hbm_bytes_per_step": int((2 * fetch + write) * 1024),
                  "fetch_size_kb_per_step": fetch, "write_size_kb_per_step": write, "kernels": per_kernel,
+                 "sq_per_step": dict(sq, all_insts=sum(sq.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))),
                  "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on python3 bench.py --steps 2 --warmup 1 --mode %s --no-other-mode; "
                            "sum over all kernels of one step (input generator and torch's own kernels left out); FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE exact; collected %s" % (mode, os.popen("date -u +%Y-%m-%dT%H:%MZ").read().strip())}
     print(mode, "HBM bytes per step", res[mode]["hbm_bytes_per_step"])
+# two contexts: kernel stats and the bench line of the profiled run
+rows = []
+for f in glob.glob(out + "/hpc2ctx/stats/*/*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+with open(out + "/hpc2ctx_kernel_stats.csv", "w") as o:
+    o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 6 --warmup 2 --mode hpc --contexts 2 --no-other-mode --no-cpu-baseline --verify-reads 0\n")
+    o.write("# (the one-context run of the same process comes first: 8 calls x 6 chunks; then 2 x 2 warm-up calls and 6 timed calls through two chained contexts)\n")
+    try:
+        o.write("# bench line of this run: " + [l for l in open(out + "/hpc2ctx.stats.log") if l.startswith("{")][-1][:600] + "\n")
+    except Exception:
+        pass
+    o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+    for r in rows:
+        n = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
+        o.write('"%s",%s,%s,%s,%s\n' % (n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
 json.dump(res["hpc"], open(out + "/traffic_hpc.json", "w"), indent=1)
 json.dump(res["regular"], open(out + "/traffic_regular.json", "w"), indent=1)
 PY
