@@ -357,7 +357,9 @@ s2k_status enqueue(s2k_ctx *ctx) {
         // chunks (the Regular-family modes, whose k-min-mer kernel costs the minimizer kernel beside it more, still do best with eight)
         // (round 4 gave a chained context two chunks for Hpc; with round 5's compaction that is the worst choice -- 6.62 ms per step against 6.25 with four
         // or six, profiles/r05_chunks_two_ctx.txt -- so chained and unchained calls are cut alike)
-        n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? 6u : 8u);
+        // Regular family: its minimizer kernel runs 16 waves per CU and leaves the k-min-mer kernel no room beside it (s2k_tile_impl.h: tw()): one
+        // launch of each, the k-min-mer stage behind the minimizer kernel on the caller's stream
+        n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? 6u : 1u);
         const uint64_t min_chunk = ctx->desc_chunks ? 64 : 12 * 3072; // tiles: a dozen per resident wave (a forced count -- tests -- only needs 64)
         if ((uint64_t)n_chunks * min_chunk > n_tiles) n_chunks = (uint32_t)(n_tiles / min_chunk);
         if (n_chunks < 1) n_chunks = 1;

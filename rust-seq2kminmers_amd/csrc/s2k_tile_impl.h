@@ -66,8 +66,17 @@ namespace {
 #ifndef S2K_TW
 #define S2K_TW 12
 #endif
-constexpr int TW = S2K_TW;                                 // waves per block = all the waves of a CU (three per SIMD): ONE block per CU shares the two seed
-                                                       // tables (4 KiB once instead of three times)
+#ifndef S2K_TW_REG
+#define S2K_TW_REG 16
+#endif
+// waves per block = all the waves of a CU: ONE block per CU shares the seed tables.  Hpc: 12 = three per SIMD (12 KB of LDS per wave: the rows of the
+// back-map beside the tile buffer), and the k-min-mer kernel's blocks run BESIDE it in what is left of the CU.  Regular family (Regular, Simd): 16 = four
+// per SIMD (9984 B per wave), nothing fits beside them, and the k-min-mer stage runs BEHIND the minimizer kernel, one launch of each per call:
+// the fourth wave buys the minimizer kernel 8 % (4.32 -> 3.96 ms per 10 Gbp), which since round 5 is more than running the k-min-mer kernel beside a
+// three-wave block saves (profiles/r05_regular_occupancy.txt; round 4 measured the two equal).
+template <bool HPC> constexpr int tw() { return HPC ? S2K_TW : S2K_TW_REG; }
+template <bool HPC> constexpr int waves_per_simd() { return tw<HPC>() / 4; }
+static_assert(S2K_TW % 4 == 0 && S2K_TW_REG % 4 == 0, "whole waves per SIMD");
 constexpr int HS_OFF = 16;                             // data starts here; byte HS_OFF-1 absorbs "slot -1" stores
 constexpr int BUF_BYTES = HS_OFF + TILE_BASES + 128;   // tile + halo / window slack
 #ifndef S2K_CAPP
@@ -85,10 +94,10 @@ constexpr int MAX_L_TILED = 64;
 #ifndef S2K_REDERIVE_GROUP
 #define S2K_REDERIVE_GROUP 4 // bases a lane of a re-derivation quad fetches at a time (8 = all of them at once: measured equal, profiles/r05_ab_rederive.txt)
 #endif
-constexpr int LISTCAP_REG = S2K_LISTCAP;                       // hits handled per dense batch (Regular: 184 +- 13 per tile)
+constexpr int LISTCAP_REG = S2K_TW_REG > 12 ? 216 : S2K_LISTCAP; // hits handled per dense batch (Regular: 184 +- 13 per tile; 216 = what 16 waves' LDS leaves)
 constexpr int LISTCAP_HPC = 192;                                      // ... Hpc: 137 +- 11 per tile of uniform ACGT; the 128 bytes pay for the wider rows of the back-map
 template <bool HPC> constexpr int listcap() { return HPC ? LISTCAP_HPC : LISTCAP_REG; }
-constexpr int JOBCAP = S2K_JOBCAP;                             // queued hash re-derivations per flush
+template <bool HPC> constexpr int jobcap() { return !HPC && S2K_TW_REG > 12 ? 16 : S2K_JOBCAP; } // queued hash re-derivations per flush
 #ifndef S2K_REG_LA
 #define S2K_REG_LA 1
 #endif
@@ -124,14 +133,14 @@ template <bool HPC>
 struct alignas(16) WaveLdsT : std::conditional<HPC, HpcLds, NoHpcLds>::type {
     uint8_t buf[BUF_BYTES];
     uint16_t list[listcap<HPC>()]; // validated hits of the current batch: tile-local hash position (bits 0-13), ascending; bit 15 = hash must be re-derived
-    uint16_t jobx[JOBCAP];    // hits whose hash must be re-derived: tile-local position ...
-    uint16_t jobslot[JOBCAP]; // ... and index of the hit among the tile's hits
+    uint16_t jobx[jobcap<HPC>()];    // hits whose hash must be re-derived: tile-local position ...
+    uint16_t jobslot[jobcap<HPC>()]; // ... and index of the hit among the tile's hits
     int16_t hb[NBL];         // read starts inside the tile, as hash-space positions (ascending; 0 .. TILE_BASES)
     uint16_t rs16[NBL];      // rs16[i] = read_off[r0 + i] - t0 for the read starts inside the tile (i >= 1; read r0 starts at rs0, kept in a register)
 };
 #ifdef S2K_PROFILE // phase accumulators of the PROFILE build (see S2K_STAMP): 16 x 8 B per wave behind the waves' buffers
 typedef __attribute__((address_space(3))) unsigned long long *ph_ptr_t;
-constexpr int PROFILE_LDS_BYTES = TW * 16 * 8;
+constexpr int PROFILE_LDS_BYTES = 16 * 16 * 8;
 #else
 typedef uint64_t *ph_ptr_t;
 constexpr int PROFILE_LDS_BYTES = 0;
@@ -154,10 +163,10 @@ constexpr int SEL8_OFF = SEED_TABLE_BYTES, SEL8_BYTES = S2K_SEL8 ? 256 * 8 : 0;
 constexpr int PK4_OFF = SEL8_OFF + SEL8_BYTES, PK4_BYTES = S2K_PASS2_ACC ? 16 * 8 : 0;
 template <bool HPC> constexpr int table_bytes() { return SEED_TABLE_BYTES + (HPC ? SEL8_BYTES + PK4_BYTES : 0); }
 template <bool HPC>
-constexpr int block_lds_bytes() { return table_bytes<HPC>() + TW * (int)sizeof(WaveLdsT<HPC>) + PROFILE_LDS_BYTES; }
-// one block of TW = 12 waves per CU: it may use the whole 160 KiB (MI355X_MICROARCH.md: "a single workgroup may declare all 160 KiB")
+constexpr int block_lds_bytes() { return table_bytes<HPC>() + tw<HPC>() * (int)sizeof(WaveLdsT<HPC>) + PROFILE_LDS_BYTES; }
+// one block of tw<HPC>() waves per CU: it may use the whole 160 KiB (MI355X_MICROARCH.md: "a single workgroup may declare all 160 KiB")
 #ifndef S2K_EXPERIMENT
-static_assert(block_lds_bytes<true>() <= 160 * 1024, "the block of a CU must fit its 160 KiB of LDS");
+static_assert(block_lds_bytes<true>() <= 160 * 1024 && block_lds_bytes<false>() <= 160 * 1024, "the block of a CU must fit its 160 KiB of LDS");
 #endif
 
 // inclusive scan over the 64 lanes with DPP row shifts / broadcasts (no LDS round trips)
@@ -514,9 +523,6 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
 // (tools/phases.sh).  The 16 accumulators of a wave live in LDS (128 B per wave behind the waves' buffers; lane 0 adds to them):
 // in registers (rounds 2-3) they cost 32 VGPRs, i.e. the third wave per SIMD -- and what a phase costs at two waves per SIMD is
 // not what it costs at three.  A stamp is ~8 instructions and drains lgkmcnt; 16 of them per tile perturb the kernel by ~3 %.
-#ifndef S2K_WAVES_PER_SIMD
-#define S2K_WAVES_PER_SIMD 3
-#endif
 #ifdef S2K_PROFILE
 #define S2K_STAMP(i)                                                                     \
     do {                                                                                 \
@@ -1320,7 +1326,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
 #endif
             if (sem.dbg_skip & 64) jobs = 0;
             while (jobs) { // wave-uniform: queue up to JOBCAP jobs, flush, queue the rest
-                const uint32_t room = (uint32_t)JOBCAP - njobs;
+                const uint32_t room = (uint32_t)jobcap<HPC>() - njobs;
                 const uint32_t rank = (uint32_t)__popcll(jobs & ((1ull << lane) - 1ull));
                 const bool minej = need && ((jobs >> lane) & 1ull) && rank < room;
                 if (minej) {
@@ -1437,7 +1443,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
 // path except in the first iteration.
 // DESC: the descriptor path (8-byte records + one word and a segment list per tile, see dense_phase); else the legacy records.
 template <int L, bool HPC, bool DESC>
-__global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_kernel(
+__global__ __launch_bounds__(64 * tw<HPC>(), waves_per_simd<HPC>()) void tile_minimizer_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases,
     uint64_t n_tiles, const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
     uint64_t *__restrict__ tile_rec_off, uint32_t *__restrict__ tile_cnt, uint32_t *mn_cnt, Counts *counts,
@@ -1451,6 +1457,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void tile_minimizer_ke
     const int lane0 = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: everything per tile is scalar
     int lane = lane0; // re-made opaque at the top of every tile (see the loop): nothing derived from the lane index is loop-invariant
     const uint32_t l = L > 0 ? (uint32_t)L : sem.l;
+    constexpr int TW = tw<HPC>();
     for (int c = threadIdx.x; c < 256; c += 64 * TW) {
         uint32_t cc = c;
         // Simd result semantics map bytes by their low nibble (src/nthash_avx512_32.rs:178-193)
@@ -1831,6 +1838,7 @@ hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t 
                            uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
                            uint64_t *tile_rec_off, uint32_t *tile_cnt, uint32_t *mn_cnt, Counts *counts, const Desc *desc, uint64_t tile_begin) {
     auto kern = tile_minimizer_kernel<L, HPC, DESC>;
+    constexpr int TW = tw<HPC>();
     const int lds = block_lds_bytes<HPC>();
     // per instantiation AND per device: function attributes and occupancy belong to the device the module is loaded on
     // (contexts on different threads may launch concurrently: the cache is filled under a lock)
