@@ -185,7 +185,9 @@ __device__ inline uint32_t dk_incl_scan(uint32_t v) {
 __device__ inline uint32_t dk_lane(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 
 // KT: compile-time k (the window loop is unrolled and reads the ring at constant offsets), or 0: run-time k <= 32
-template <int KT>
+// FULL: the caller wants all four k-min-mer arrays and no minimizer triples (the common call): no per-array tests in the round loop, and a tile whose
+// windows all fit the arrays' capacity (every tile of a call that fits) stores at 32-bit offsets from per-tile scalar bases without a per-lane test
+template <int KT, bool FULL>
 __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t tile_begin, uint64_t tile_end, uint64_t n_tiles, uint64_t n_reads, Desc dz,
                                                                         Records rec, Counts *counts) {
     __shared__ unsigned long long s_ring[DK_WAVES][64 + DK_KMAX];
@@ -296,6 +298,13 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
     }
     uint32_t jprev = p_in && (uint32_t)lane >= 64u - K1 ? s_jcar[w][lane - (64u - K1)] : 0u; // "the round before the first": the k-1 minimizers before the tile
     uint64_t xacc = 0;
+    // one or two read starts per tile as a rule: their hit indices as scalars (a segment that does not exist starts "never"), no LDS walk per round
+    const uint32_t sb1 = nb >= 1u ? dk_lane(segstart, 1) : 0xFFFFFFFFu, sb2 = nb >= 2u ? dk_lane(segstart, 2) : 0xFFFFFFFFu;
+    // FULL: do all windows of the tile fit the caller's arrays?  (G + Wt <= capacity: then nothing is tested per lane)
+    const bool tile_fits = FULL && G + (uint64_t)Wt <= dz.km_capacity;
+    unsigned long long *const t_hash = dz.o_hash + G;
+    uint32_t *const t_start = dz.o_start + G, *const t_end = dz.o_end + G;
+    uint8_t *const t_rev = dz.o_rev + G;
     for (uint32_t i0 = 0; i0 < N; i0 += 64) {
         const uint32_t i = i0 + lane;
         const bool act = i < N;
@@ -304,9 +313,9 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
             nh32 = rec.hash[base + i + 64];
             npos = rec.j[base + i + 64];
         }
-        uint32_t c = 0;
-#pragma nounroll // (one or two read starts per tile as a rule: unrolled 31 times, the loop was most of the kernel's code)
-        for (uint32_t s = 1; s <= nb; s++) c += (s_segb[w][s] <= i); // wave-uniform trip count, LDS broadcast
+        uint32_t c = (uint32_t)(sb1 <= i) + (uint32_t)(sb2 <= i);
+#pragma nounroll // (more than two read starts in a tile: the walk; unrolled 31 times, the loop was most of the kernel's code)
+        for (uint32_t s = 3; s <= nb; s++) c += (s_segb[w][s] <= i); // wave-uniform trip count, LDS broadcast
         const uint64_t rstart = s_rs[w][c];
         const uint32_t j = (uint32_t)(t0 + (pos & 0x3FFFu) - rstart);
         const uint32_t jend = j + (pos >> 14);
@@ -376,16 +385,24 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
         const uint32_t jstart = (uint32_t)lane >= K1 ? jsame : jbefore;
         const uint64_t hmin = f < rvv ? f : rvv;
         if (win) {
-            const uint64_t o = G + (uint64_t)(int64_t)((int32_t)i + s_adj[w][c]);
+            const uint32_t ot = (uint32_t)((int32_t)i + s_adj[w][c]); // index among the tile's windows (>= 0 for a window)
             xacc ^= hmin;
-            if (o < dz.km_capacity) {
-                if (dz.o_hash) dz.o_hash[o] = hmin;
-                if (dz.o_start) dz.o_start[o] = jstart;
-                if (dz.o_end) dz.o_end[o] = jend;
-                if (dz.o_rev) dz.o_rev[o] = (uint8_t)(rvv < f); // src/lib.rs:250-251
+            if (tile_fits) { // (wave-uniform) FULL and everything fits: scalar base + 32-bit offset, no tests
+                t_hash[ot] = hmin;
+                t_start[ot] = jstart;
+                t_end[ot] = jend;
+                t_rev[ot] = (uint8_t)(rvv < f); // src/lib.rs:250-251
+            } else {
+                const uint64_t o = G + (uint64_t)ot;
+                if (o < dz.km_capacity) {
+                    if (dz.o_hash) dz.o_hash[o] = hmin;
+                    if (dz.o_start) dz.o_start[o] = jstart;
+                    if (dz.o_end) dz.o_end[o] = jend;
+                    if (dz.o_rev) dz.o_rev[o] = (uint8_t)(rvv < f);
+                }
             }
         }
-        if (dz.mn_capacity && act) { // optional minimizer triples (NtHashHPCIterator::Item, src/nthash_hpc.rs:193)
+        if (!FULL && dz.mn_capacity && act) { // optional minimizer triples (NtHashHPCIterator::Item, src/nthash_hpc.rs:193)
             const uint64_t g = Gmn + i;
             if (g < dz.mn_capacity) {
                 dz.o_mn_j[g] = j;
@@ -435,11 +452,14 @@ hipError_t launch_desc_kminmers(uint64_t tile_begin, uint64_t tile_end, uint64_t
 #ifdef S2K_DEBUG_KNOBS
     if (const char *e = getenv("S2K_DEBUG_KM_LDS")) pad = (unsigned)atoi(e);
 #endif
+    const bool full = dz.o_hash && dz.o_start && dz.o_end && dz.o_rev && dz.mn_capacity == 0;
+#define S2K_KM_GO(KT, F) hipLaunchKernelGGL((desc_kminmer_kernel<KT, F>), g, b, pad, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts)
     switch (dz.k) { // the benchmark's k and the reference demo's (src/main.rs:13-48) get an unrolled window loop
-    case 10: hipLaunchKernelGGL(desc_kminmer_kernel<10>, g, b, pad, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
-    case 5: hipLaunchKernelGGL(desc_kminmer_kernel<5>, g, b, pad, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
-    default: hipLaunchKernelGGL(desc_kminmer_kernel<0>, g, b, pad, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts); break;
+    case 10: if (full) S2K_KM_GO(10, true); else S2K_KM_GO(10, false); break;
+    case 5: if (full) S2K_KM_GO(5, true); else S2K_KM_GO(5, false); break;
+    default: if (full) S2K_KM_GO(0, true); else S2K_KM_GO(0, false); break;
     }
+#undef S2K_KM_GO
     return hipGetLastError();
 }
 
