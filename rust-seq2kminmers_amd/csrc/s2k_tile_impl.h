@@ -11,7 +11,8 @@
 //    are cleared from the hit masks afterwards, so ragged reads cost nothing in the hot loop.
 //  * Persistent waves, tiles dealt DYNAMICALLY: a wave takes its first three tiles statically (the software pipeline
 //    is three deep) and every later one from one of 64 cursors in global memory (one atomic per tile, issued at the
-//    top of an iteration and looked at after the hash loop).  Everything per tile lives in SGPRs.
+//    top of an iteration and looked at after the hash loop).  Everything per tile lives in SGPRs.  One block per CU: 12
+//    waves for the Hpc modes, 16 for the Regular family (tw<HPC>()).
 //  * A tile's 9344 bytes (9216 + 128 B look-ahead) go from global memory STRAIGHT into the wave's LDS buffer
 //    (global_load_lds_dwordx4, issued from inline asm, 1 KiB per wave-instruction, no registers, no ds_write) while
 //    the previous tile's one-lane-per-hit rounds run; the top of an iteration waits for them with a COUNTED
@@ -37,11 +38,14 @@
 //    the read starts kept in LDS and writes 16-byte records for s2k_kminmer.hip.  No global LOAD sits in the round loop: one
 //    would make the compiler drain every outstanding store of the previous round.
 //  * Hpc mode first compacts the tile's run heads in place in LDS (SWAR byte compares -> v_dot4 nibbles -> per-lane
-//    flag masks in natural bit order, popcounts, one wave scan, overwrite-style byte stores), appends the l run heads
-//    that follow the tile (first from the staged look-ahead, then by a loop over the stream, so arbitrarily long
-//    homopolymers are fine), and then runs the same hash loop over the compacted bytes.  Raw positions are recovered
-//    for hits only, from the per-lane flag masks (owner-lane hint table + select-nth-bit).  Read starts are forced run
-//    heads: they are OR-ed into the flag masks; the staged bytes are never modified, so ANY byte value is fine.
+//    flag masks in natural bit order, popcounts, one wave scan; then per dword ONE v_perm_b32 packs its run heads, a
+//    64-bit window collects them and an aligned ds_or_b32 per step puts them in place -- round 5; rounds 1-4: one byte
+//    store per raw byte), appends the l run heads that follow the tile (first from the staged look-ahead, then by a
+//    loop over the stream, so arbitrarily long homopolymers are fine), and then runs the same hash loop over the
+//    compacted bytes.  Raw positions are recovered for hits only: a directory of every 64th run head names the raw
+//    lane, that lane's row (flag words, prefix, cumulative word counts) names the flag word, a 2 KiB table the bit
+//    (HpcLds, hpc_rawpos2).  Read starts are forced run heads: they are OR-ed into the flag masks; the staged bytes
+//    are never modified, so ANY byte value is fine.
 //  * HpcSimd result semantics need the run count of the whole read where it ends: every tile publishes how many run heads of
 //    the read continuing past its end it holds, the tile in which the read ends looks back (lookback_heads) -- no second pass.
 //  * Records go to a fixed per-tile slab (mean + 6 sigma); only a tile with more hits takes space from a
@@ -118,13 +122,16 @@ constexpr int NPRE = 10;                               // 16 B/lane loads that s
 // holds fewer than 64 heads --, and that lane's row says how many heads lie before it (prefix) and before each of its flag words (cum),
 // so that ONE flag word is fetched and searched (sel8).  (Rounds 2-4: a hint per hash lane, a search over the prefixes, two whole rows of
 // five words and a popcount walk over them per head -- nine dependent LDS round trips and ~250 instructions per round of 64 hits.)
-constexpr int ROW_W = 6, ROW_PFX = 4, ROW_CUM = 5, N_ROWS = 66, SD_SHIFT = 6;
+#ifndef S2K_SD_SHIFT
+#define S2K_SD_SHIFT 6
+#endif
+constexpr int ROW_W = 6, ROW_PFX = 4, ROW_CUM = 5, N_ROWS = 66, SD_SHIFT = S2K_SD_SHIFT;
 struct HpcLds {
     uint32_t row[N_ROWS][ROW_W]; // raw lane o: words 0-3 = run-head flags of its bytes 0..127 (bit i of word g <-> byte 32 g + i), word 4 = flags of bytes
                                  // 128..143 | exclusive prefix of the lanes' head counts << 16, word 5 = heads in words 0..g, one byte per g = 0..3.
                                  // Rows 64, 65: sentinels (prefix = R, the tile's head count)
     uint32_t halo_pos[64];       // tile-relative raw offsets of the run heads that follow the tile
-    uint8_t sd[160];             // sd[m] = raw lane that owns run head 64 m (m <= (R - 1) / 64 <= 143)
+    uint8_t sd[SD_SHIFT == 6 ? 160 : 288]; // sd[m] = raw lane that owns run head 64 m (m <= (R - 1) / 64 <= 143)
 };
 static_assert(sizeof(HpcLds) % 16 == 0, "the tile buffer behind it is read 16 bytes at a time");
 struct NoHpcLds {};
@@ -543,7 +550,7 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
 
 // ------------------------------------------------------------------------------------------------
 // Hpc pre-stage: in-place run-head compaction of the staged tile.  Returns R_t (run heads owned by
-// the tile) and leaves D[0..R_t) = head bytes, D[R_t..R_t+halo_n) = following heads, S.fm / S.hbase /
+// the tile) and leaves D[0..R_t) = head bytes, D[R_t..R_t+halo_n) = following heads, S.row / S.sd /
 // S.halo_pos for the back-map.
 //
 // Run-head flags are kept in NATURAL order: bit i of the lane's 144-bit mask (five words) <-> raw byte i of the
@@ -558,7 +565,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
                                                 uint32_t prev_byte0, bool forced0, const Sem &sem, ph_ptr_t ph,
                                                 uint64_t &stamp) {
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    // 1. read starts strictly inside the tile -> forced run heads, OR-ed into S.fm (cleared by the caller before the
+    // 1. read starts strictly inside the tile -> forced run heads, OR-ed into S.row (words 0-4, cleared by the caller before the
     //    tile was staged).  bpos0 = read_off[r0 + 1 + lane] was fetched ahead.
     {
         uint64_t sp = bpos0;
@@ -659,48 +666,108 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     //    of a dword with v_perm_b32 and storing them with one unaligned dword store was 2x slower than this.)
 #if S2K_PASS2_ACC
     // 4. pass 2 (round 5): the run heads of a dword are packed to its low end by ONE v_perm_b32 (selector and count from the 16-entry table
-    //    pk4, indexed by the dword's flag nibble), merged into a 64-bit window at the lane's fill level, and the window's low dword is OR-ed
-    //    into the (zeroed) buffer at an ALIGNED address every step -- ds_or_b32: partial states of a dword are subsets of its final state,
-    //    so storing early and often is harmless, and the dwords two lanes share (a lane's run heads begin and end at any byte) merge by
-    //    themselves.  36 aligned LDS operations per lane instead of 144 byte stores whose data-dependent slots collided in the banks: a byte store
-    //    cost 5.5 units of a plain vector instruction's 1.0 where it ran (3.1 without the conflicts; profiles/r05_instruction_costs.txt).
+    //    pk4, indexed by the dword's flag nibble) and merged into a 64-bit window at the lane's fill level; the window's low dword goes into the
+    //    (zeroed) buffer at an ALIGNED address.  36 aligned LDS operations per lane instead of 144 byte stores whose data-dependent slots collided in
+    //    the banks (a byte store cost 5.5 units of a plain vector instruction's 1.0 where it ran, 3.1 without the conflicts:
+    //    profiles/r05_instruction_costs.txt).  The dwords two lanes share (a lane's run heads begin and end at any byte) are merged in one of two ways:
+    //    DENSE tiles (>= 0.6 run heads per base; uniform-random ACGT has 0.75): the low dword is OR-ed in every step (ds_or_b32) -- partial
+    //      states of a dword are subsets of its final state, so storing early and often is harmless, and shared dwords merge by themselves;
+    //    SPARSE tiles (HiFi-like reads, 0.29): with few run heads per step the same dword would be OR-ed over and over (7.7 -> 8.9 ms per 15 Gbp:
+    //      atomics on one address serialise), so a dword is written plainly by the lane that COMPLETES it, the moment it does -- with zeros where other
+    //      lanes' bytes go --, every other step's store goes to a per-lane dump slot (the hit list's space, dead during the compaction), and what a lane
+    //      holds of a dword it does not complete is OR-ed in after the loop.  (Dense tiles that way: +1 % kernel time, profiles/r05_ab_pass2_sparse.txt.)
     {
         typedef __attribute__((address_space(3))) const unsigned long long *lds_cu64;
         uint4 *zp = reinterpret_cast<uint4 *>(D + lane_off);
 #pragma unroll
         for (int p = 0; p < 9; p++) zp[p] = make_uint4(0, 0, 0, 0); // (every lane holds its raw chunk in registers)
         asm volatile("" ::: "memory");
-        uint32_t waddr = (uint32_t)(uintptr_t)(lds_u8 *)D + (base & ~3u); // aligned LDS address of the dword being filled
-        uint32_t fill8 = 8u * (base & 3u), lo = 0;                        // bits of it that belong to the lanes before this one
-        constexpr int GRP2 = S2K_PASS2_GROUP; // table entries fetched at a time: one LDS round trip per group instead of one per dword
+#if S2K_PASS2_ACC == 3 // (experiment) ONE code path: ds_or_b32 every step, at the dword being filled -- or, in a sparse tile and while it is incomplete, at the dump slot
+        {
+            const bool sparse = 10u * R < 6u * tile_len; // (wave-uniform)
+            uint32_t waddr = (uint32_t)(uintptr_t)(lds_u8 *)D + (base & ~3u);
+            uint32_t fill8 = 8u * (base & 3u), lo = 0;
+            const uint32_t dump = (uint32_t)(uintptr_t)(lds_u8 *)reinterpret_cast<uint8_t *>(&S.list[0]) + 4u * (uint32_t)lane;
+            constexpr int GRP2 = S2K_PASS2_GROUP;
 #pragma unroll
-        for (int d0 = 0; d0 < 36; d0 += GRP2) {
-            unsigned long long e[GRP2];
+            for (int d0 = 0; d0 < 36; d0 += GRP2) {
+                unsigned long long e[GRP2];
 #pragma unroll
-            for (int dd = 0; dd < GRP2; dd++) {
-                const int d = d0 + dd, g = d >> 3, sft = 4 * (d & 7);
-                if (d < 36) {
-                    const uint32_t idx8 = sft >= 3 ? (fmk[g] >> (sft - 3)) & 0x78u : (fmk[g] << (3 - sft)) & 0x78u; // 8 x the dword's flag nibble
-                    e[dd] = *reinterpret_cast<lds_cu64>((uint32_t)PK4_OFF + idx8);
+                for (int dd = 0; dd < GRP2; dd++) {
+                    const int d = d0 + dd, g = d >> 3, sft = 4 * (d & 7);
+                    if (d < 36) {
+                        const uint32_t idx8 = sft >= 3 ? (fmk[g] >> (sft - 3)) & 0x78u : (fmk[g] << (3 - sft)) & 0x78u;
+                        e[dd] = *reinterpret_cast<lds_cu64>((uint32_t)PK4_OFF + idx8);
+                    }
+                }
+#pragma unroll
+                for (int dd = 0; dd < GRP2; dd++) {
+                    const int d = d0 + dd;
+                    if (d < 36) {
+                        const uint32_t packed = __builtin_amdgcn_perm(0u, c[d], (uint32_t)e[dd]);
+                        const unsigned long long win = (unsigned long long)packed << fill8;
+                        lo |= (uint32_t)win;
+                        fill8 += (uint32_t)(e[dd] >> 32);
+                        const bool full = fill8 >= 32u;
+                        const uint32_t sa = (full || !sparse) ? waddr : dump;
+                        asm volatile("ds_or_b32 %0, %1" ::"v"(sa), "v"(lo) : "memory");
+                        lo = full ? (uint32_t)(win >> 32) : lo;
+                        waddr += full ? 4u : 0u;
+                        fill8 &= 31u;
+                    }
                 }
             }
-#pragma unroll
-            for (int dd = 0; dd < GRP2; dd++) {
-                const int d = d0 + dd;
-                if (d < 36) {
-                    const uint32_t packed = __builtin_amdgcn_perm(0u, c[d], (uint32_t)e[dd]);
-                    const unsigned long long win = (unsigned long long)packed << fill8; // fill8 < 32
-                    lo |= (uint32_t)win;
-                    asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory");
-                    fill8 += (uint32_t)(e[dd] >> 32);
-                    const bool full = fill8 >= 32u;
-                    lo = full ? (uint32_t)(win >> 32) : lo;
-                    waddr += full ? 4u : 0u;
-                    fill8 &= 31u;
-                }
-            }
+            asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory");
         }
-        asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory"); // what a last completed dword left over
+#else
+        const uint32_t(&fmk_)[5] = fmk;
+        auto pass2 = [&](auto sparse_c) {
+            constexpr bool SPARSE = decltype(sparse_c)::value;
+            // (opaque copies of the masks per instantiation: what the two have in common -- table look-ups, packed dwords -- is otherwise hoisted above
+            // the branch and held across it: 118 -> 143 registers)
+            uint32_t fmk[5] = {fmk_[0], fmk_[1], fmk_[2], fmk_[3], fmk_[4]};
+#pragma unroll
+            for (int g = 0; g < 5; g++) asm volatile("" : "+v"(fmk[g]));
+            uint32_t waddr = (uint32_t)(uintptr_t)(lds_u8 *)D + (base & ~3u); // aligned LDS address of the dword being filled
+            uint32_t fill8 = 8u * (base & 3u), lo = 0;                        // bits of it that belong to the lanes before this one
+            const uint32_t dump = (uint32_t)(uintptr_t)(lds_u8 *)reinterpret_cast<uint8_t *>(&S.list[0]) + 4u * (uint32_t)lane;
+            constexpr int GRP2 = S2K_PASS2_GROUP; // table entries fetched at a time: one LDS round trip per group instead of one per dword
+#pragma unroll
+            for (int d0 = 0; d0 < 36; d0 += GRP2) {
+                unsigned long long e[GRP2];
+#pragma unroll
+                for (int dd = 0; dd < GRP2; dd++) {
+                    const int d = d0 + dd, g = d >> 3, sft = 4 * (d & 7);
+                    if (d < 36) {
+                        const uint32_t idx8 = sft >= 3 ? (fmk[g] >> (sft - 3)) & 0x78u : (fmk[g] << (3 - sft)) & 0x78u; // 8 x the dword's flag nibble
+                        e[dd] = *reinterpret_cast<lds_cu64>((uint32_t)PK4_OFF + idx8);
+                    }
+                }
+#pragma unroll
+                for (int dd = 0; dd < GRP2; dd++) {
+                    const int d = d0 + dd;
+                    if (d < 36) {
+                        const uint32_t packed = __builtin_amdgcn_perm(0u, c[d], (uint32_t)e[dd]);
+                        const unsigned long long win = (unsigned long long)packed << fill8; // fill8 < 32
+                        lo |= (uint32_t)win;
+                        if constexpr (!SPARSE) asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory");
+                        fill8 += (uint32_t)(e[dd] >> 32);
+                        const bool full = fill8 >= 32u;
+                        if constexpr (SPARSE) {
+                            const uint32_t sa = full ? waddr : dump;
+                            asm volatile("ds_write_b32 %0, %1" ::"v"(sa), "v"(lo) : "memory");
+                        }
+                        lo = full ? (uint32_t)(win >> 32) : lo;
+                        waddr += full ? 4u : 0u;
+                        fill8 &= 31u;
+                    }
+                }
+            }
+            asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory"); // what the lane holds of a dword it did not complete
+        };
+        if (10u * R < 6u * tile_len) pass2(std::true_type{}); // (wave-uniform)
+        else pass2(std::false_type{});
+#endif
     }
 #else
     {
@@ -783,11 +850,6 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
 }
 
 
-// Back-map of one Hpc hit: tile-relative raw offsets of run heads x and x + l (x < R; x + l may be one of the
-// run heads that follow the tile).  The owner raw lane of a head is the last o with hbase[o] <= head; S.hl
-// brackets it to the raw lanes spanned by the head's hash lane.  Head x + l is found FROM head x: it lies l heads
-// further on, i.e. in the same raw lane or in the next one unless a lane holds fewer than l heads (long homopolymers:
-// those hits search again) -- round 2 ran two full searches side by side (~100 instructions each per round of 64 hits).
 // Back-map of one Hpc hit (v2, see HpcLds): tile-relative raw offsets of run heads x and y = x + l (x < R; y may be one of the run heads
 // that follow the tile).  Four LDS round trips, both heads side by side: directory -> {prefix, cum} of the three candidate lanes ->
 // the one flag word that holds the head -> sel8.
@@ -906,7 +968,7 @@ __device__ __forceinline__ uint32_t lookback_heads(const uint32_t *W, uint64_t t
     return sum;
 }
 
-// ... and the word itself (HpcSimd only; after hpc_compact: S.hbase / S.fm hold the tile's run heads).  last_start: where the
+// ... and the word itself (HpcSimd only; after hpc_compact: S.row holds the tile's run heads).  last_start: where the
 // last read that starts in (t0, tile end] starts, if there is one.
 template <class WL>
 __device__ __forceinline__ void publish_tile_heads(uint32_t *W, uint64_t t, const WL &S, uint32_t nh, uint64_t t0, uint32_t tile_len,
