@@ -355,11 +355,12 @@ s2k_status enqueue(s2k_ctx *ctx) {
         // measured: profiles/r03_ab_chunks.txt (one context: more chunks = a smaller exposed tail, fewer = fewer chunk boundaries) and, for a chained
         // context, profiles/r04_chained_chunks.txt: its tail runs beside the other context's minimizer kernels anyway, so the Hpc modes take two
         // chunks (the Regular-family modes, whose k-min-mer kernel costs the minimizer kernel beside it more, still do best with eight)
-        // (round 4 gave a chained context two chunks for Hpc; with round 5's compaction that is the worst choice -- 6.62 ms per step against 6.25 with four
-        // or six, profiles/r05_chunks_two_ctx.txt -- so chained and unchained calls are cut alike)
+        // Hpc: six chunks; FOUR for a chained context (s2k_chain_after), whose tail -- the last chunk's k-min-mer kernel, alone on the device -- is covered by
+        // the other context's next call, so that fewer chunk boundaries pay: 6.15 against 6.23-6.26 ms per step, and 6.41 against 6.46 the other way round
+        // for an unchained one (profiles/r05_chunks_final.txt; two chunks, round 4's choice for chained calls, swung between best and worst as the kernels changed)
         // Regular family: its minimizer kernel runs 16 waves per CU and leaves the k-min-mer kernel no room beside it (s2k_tile_impl.h: tw()): one
         // launch of each, the k-min-mer stage behind the minimizer kernel on the caller's stream
-        n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? 6u : 1u);
+        n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? (ctx->chain_prev ? 4u : 6u) : 1u);
         const uint64_t min_chunk = ctx->desc_chunks ? 64 : 12 * 3072; // tiles: a dozen per resident wave (a forced count -- tests -- only needs 64)
         if ((uint64_t)n_chunks * min_chunk > n_tiles) n_chunks = (uint32_t)(n_tiles / min_chunk);
         if (n_chunks < 1) n_chunks = 1;
