@@ -352,15 +352,17 @@ s2k_status enqueue(s2k_ctx *ctx) {
     // a quarter of the issue slots and some LDS free).  A chunk is at least a few tiles per resident wave.
     uint32_t n_chunks = 1;
     if (use_desc) {
-        // measured: profiles/r03_ab_chunks.txt (one context: more chunks = a smaller exposed tail, fewer = fewer chunk boundaries) and, for a chained
-        // context, profiles/r04_chained_chunks.txt: its tail runs beside the other context's minimizer kernels anyway, so the Hpc modes take two
-        // chunks (the Regular-family modes, whose k-min-mer kernel costs the minimizer kernel beside it more, still do best with eight)
-        // Hpc: six chunks; FOUR for a chained context (s2k_chain_after), whose tail -- the last chunk's k-min-mer kernel, alone on the device -- is covered by
-        // the other context's next call, so that fewer chunk boundaries pay: 6.15 against 6.23-6.26 ms per step, and 6.41 against 6.46 the other way round
-        // for an unchained one (profiles/r05_chunks_final.txt; two chunks, round 4's choice for chained calls, swung between best and worst as the kernels changed)
+        // Hpc, how many chunks: more chunks = a smaller exposed tail (the last chunk's k-min-mer kernel, alone on the device) and chunks whose records are
+        // still near when their k-min-mer kernel reads them; fewer = fewer chunk boundaries (~40 us each: waves run dry, a launch, a first tile's unhidden load).
+        // What pays is a matter of the chunk's SIZE, and differently for a chained context (s2k_chain_after), whose tail is covered by the other context's next
+        // call: measured on calls of 1 - 25 Gbp of three read shapes (profiles/r05_chunks_sizes.txt, r05_chunks_workloads.txt, r05_chunks_workloads_b.txt), a
+        // chained call does best with chunks of ~4 Gbp (10 Gbp: 2-3 chunks 6.10 ms, six 6.17-6.25; 25 Gbp: six 15.0, three 15.5), an unchained one with
+        // ~1.7 Gbp (10 Gbp: six 6.35-6.41, three 6.48-6.51), either way between two and eight.  (Rounds 3-4 used fixed counts: 6, and 2 for chained calls.)
         // Regular family: its minimizer kernel runs 16 waves per CU and leaves the k-min-mer kernel no room beside it (s2k_tile_impl.h: tw()): one
         // launch of each, the k-min-mer stage behind the minimizer kernel on the caller's stream
-        n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? (ctx->chain_prev ? 4u : 6u) : 1u);
+        uint32_t by_size = (uint32_t)((double)n_bases / (ctx->chain_prev ? 4.0e9 : 1.7e9) + 0.5);
+        by_size = by_size < 2u ? 2u : (by_size > 8u ? 8u : by_size);
+        n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? by_size : 1u);
         const uint64_t min_chunk = ctx->desc_chunks ? 64 : 12 * 3072; // tiles: a dozen per resident wave (a forced count -- tests -- only needs 64)
         if ((uint64_t)n_chunks * min_chunk > n_tiles) n_chunks = (uint32_t)(n_tiles / min_chunk);
         if (n_chunks < 1) n_chunks = 1;

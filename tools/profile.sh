@@ -73,7 +73,7 @@ for f in glob.glob(out + "/hpc2ctx/stats/*/*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
 with open(out + "/hpc2ctx_kernel_stats.csv", "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 6 --warmup 2 --mode hpc --contexts 2 --no-other-mode --no-cpu-baseline --verify-reads 0\n")
-    o.write("# (the one-context run of the same process comes first: (2 warm-up + 6 timed) calls x 6 chunks; then 2 warm-up and 6 timed calls x 4 chunks through two chained contexts)\n")
+    o.write("# (the one-context run of the same process comes first: (2 warm-up + 6 timed) calls x 6 chunks; then 2 warm-up and 6 timed calls x 3 chunks through two chained contexts)\n")
     try:
         o.write("# bench line of this run: " + [l for l in open(out + "/hpc2ctx.stats.log") if l.startswith("{")][-1][:600] + "\n")
     except Exception:
