@@ -38,8 +38,8 @@
 //    the read starts kept in LDS and writes 16-byte records for s2k_kminmer.hip.  No global LOAD sits in the round loop: one
 //    would make the compiler drain every outstanding store of the previous round.
 //  * Hpc mode first compacts the tile's run heads in place in LDS (SWAR byte compares -> v_dot4 nibbles -> per-lane
-//    flag masks in natural bit order, popcounts, one wave scan; then per dword ONE v_perm_b32 packs its run heads, a
-//    64-bit window collects them and an aligned ds_or_b32 per step puts them in place -- round 5; rounds 1-4: one byte
+//    flag masks in natural bit order, popcounts, one wave scan; then per EIGHT raw bytes two v_perm_b32 pack their run
+//    heads, and aligned LDS operations put them in place at the lane's fill level -- round 5; rounds 1-4: one byte
 //    store per raw byte), appends the l run heads that follow the tile (first from the staged look-ahead, then by a
 //    loop over the stream, so arbitrarily long homopolymers are fine), and then runs the same hash loop over the
 //    compacted bytes.  Raw positions are recovered for hits only: a directory of every 64th run head names the raw
@@ -156,19 +156,16 @@ constexpr int SEED_TABLE_BYTES = 2 * 256 * 8; // IN table at 0: {h[c], rotl(rc[c
 #ifndef S2K_SEL8
 #define S2K_SEL8 1
 #endif
-// Hpc: behind the seed tables, sel8[m][n] = index of the n-th set bit of the byte m (2 KiB): the last three levels of the back-map's
-// select-nth-set-bit are one look-up
+// Hpc: behind the seed tables, sel8[m][n] = index of the n-th set bit of the byte m, 0x0C for n >= popcount(m) (2 KiB): the last three levels of the
+// back-map's select-nth-set-bit are one look-up -- and entry m, read as two dwords, is the pair of v_perm_b32 selectors with which pass 2 of the
+// compaction packs the run heads of eight raw bytes whose flag byte is m (hpc_compact)
 constexpr int TABLE_BYTES = SEED_TABLE_BYTES; // (tools/experiments)
 constexpr int SEL8_OFF = SEED_TABLE_BYTES, SEL8_BYTES = S2K_SEL8 ? 256 * 8 : 0;
-#ifndef S2K_PASS2_GROUP
-#define S2K_PASS2_GROUP 12
-#endif
 #ifndef S2K_PASS2_ACC
-#define S2K_PASS2_ACC 1 // Hpc compaction, pass 2: 1 = register accumulator + aligned ds_or_b32 (round 5), 0 = one byte store per raw byte (rounds 1-4)
+#define S2K_PASS2_ACC 1 // Hpc compaction, pass 2: 1 = eight raw bytes per step, packed by v_perm_b32 and placed with aligned LDS operations (round 5), 0 = one byte store per raw byte (rounds 1-4)
 #endif
-// Hpc, behind sel8: pk4[n] = {v_perm_b32 selector that packs the bytes of a dword whose flag nibble is n to its low end, 8 x popcount(n)} (128 B)
-constexpr int PK4_OFF = SEL8_OFF + SEL8_BYTES, PK4_BYTES = S2K_PASS2_ACC ? 16 * 8 : 0;
-template <bool HPC> constexpr int table_bytes() { return SEED_TABLE_BYTES + (HPC ? SEL8_BYTES + PK4_BYTES : 0); }
+static_assert(!S2K_PASS2_ACC || S2K_SEL8, "pass 2 reads its v_perm_b32 selectors from sel8");
+template <bool HPC> constexpr int table_bytes() { return SEED_TABLE_BYTES + (HPC ? SEL8_BYTES : 0); }
 template <bool HPC>
 constexpr int block_lds_bytes() { return table_bytes<HPC>() + tw<HPC>() * (int)sizeof(WaveLdsT<HPC>) + PROFILE_LDS_BYTES; }
 // one block of tw<HPC>() waves per CU: it may use the whole 160 KiB (MI355X_MICROARCH.md: "a single workgroup may declare all 160 KiB")
@@ -665,109 +662,76 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     //    64 cycles per wave instruction against ~4 for ds_write_b8, tools/experiments/lds_rate.hip -- so packing the heads
     //    of a dword with v_perm_b32 and storing them with one unaligned dword store was 2x slower than this.)
 #if S2K_PASS2_ACC
-    // 4. pass 2 (round 5): the run heads of a dword are packed to its low end by ONE v_perm_b32 (selector and count from the 16-entry table
-    //    pk4, indexed by the dword's flag nibble) and merged into a 64-bit window at the lane's fill level; the window's low dword goes into the
-    //    (zeroed) buffer at an ALIGNED address.  36 aligned LDS operations per lane instead of 144 byte stores whose data-dependent slots collided in
-    //    the banks (a byte store cost 5.5 units of a plain vector instruction's 1.0 where it ran, 3.1 without the conflicts:
-    //    profiles/r05_instruction_costs.txt).  The dwords two lanes share (a lane's run heads begin and end at any byte) are merged in one of two ways:
-    //    DENSE tiles (>= 0.6 run heads per base; uniform-random ACGT has 0.75): the low dword is OR-ed in every step (ds_or_b32) -- partial
-    //      states of a dword are subsets of its final state, so storing early and often is harmless, and shared dwords merge by themselves;
+    // 4. pass 2 (round 5): eight raw bytes (two dwords) per step.  Their flag BYTE indexes sel8 -- whose entry, the positions of the byte's set bits in
+    //    order with 0x0C behind them, is at the same time the pair of v_perm_b32 selectors that packs the run heads of the eight bytes to the low end of
+    //    a 64-bit value.  Shifted to the lane's fill level that value spans up to three dwords of the (zeroed) buffer, all at ALIGNED addresses:
+    //    18 steps of 14 vector + 3 LDS instructions per lane instead of 144 byte stores whose data-dependent slots collided in the banks (a byte
+    //    store cost 5.5 units of a plain vector instruction's 1.0 where it ran, 3.1 without the conflicts: profiles/r05_instruction_costs.txt; one
+    //    dword per step through a 16-entry table, this round's first version: 22 + 4 per eight bytes, profiles/r05_ab_pass2_pairs.txt).  The dwords two
+    //    lanes share (a lane's run heads begin and end at any byte) are merged in one of two ways:
+    //    DENSE tiles (>= 0.6 run heads per base; uniform-random ACGT has 0.75): the first two dwords are OR-ed in place every step (ds_or_b32) -- partial
+    //      states of a dword are subsets of its final state, so storing early and often is harmless, and shared dwords merge by themselves -- and only
+    //      the bits beyond them are carried to the next step;
     //    SPARSE tiles (HiFi-like reads, 0.29): with few run heads per step the same dword would be OR-ed over and over (7.7 -> 8.9 ms per 15 Gbp:
     //      atomics on one address serialise), so a dword is written plainly by the lane that COMPLETES it, the moment it does -- with zeros where other
-    //      lanes' bytes go --, every other step's store goes to a per-lane dump slot (the hit list's space, dead during the compaction), and what a lane
-    //      holds of a dword it does not complete is OR-ed in after the loop.  (Dense tiles that way: +1 % kernel time, profiles/r05_ab_pass2_sparse.txt.)
+    //      lanes' bytes go --, every other store of a step goes to a per-lane dump slot (the hit list's space, dead during the compaction), the incomplete
+    //      dword is carried whole, and what a lane holds of a dword it does not complete is OR-ed in after the loop.  (Dense tiles that way: +1 % kernel
+    //      time, profiles/r05_ab_pass2_sparse.txt.)
     {
         typedef __attribute__((address_space(3))) const unsigned long long *lds_cu64;
         uint4 *zp = reinterpret_cast<uint4 *>(D + lane_off);
 #pragma unroll
         for (int p = 0; p < 9; p++) zp[p] = make_uint4(0, 0, 0, 0); // (every lane holds its raw chunk in registers)
         asm volatile("" ::: "memory");
-#if S2K_PASS2_ACC == 3 // (experiment) ONE code path: ds_or_b32 every step, at the dword being filled -- or, in a sparse tile and while it is incomplete, at the dump slot
-        {
-            const bool sparse = 10u * R < 6u * tile_len; // (wave-uniform)
-            uint32_t waddr = (uint32_t)(uintptr_t)(lds_u8 *)D + (base & ~3u);
-            uint32_t fill8 = 8u * (base & 3u), lo = 0;
-            const uint32_t dump = (uint32_t)(uintptr_t)(lds_u8 *)reinterpret_cast<uint8_t *>(&S.list[0]) + 4u * (uint32_t)lane;
-            constexpr int GRP2 = S2K_PASS2_GROUP;
-#pragma unroll
-            for (int d0 = 0; d0 < 36; d0 += GRP2) {
-                unsigned long long e[GRP2];
-#pragma unroll
-                for (int dd = 0; dd < GRP2; dd++) {
-                    const int d = d0 + dd, g = d >> 3, sft = 4 * (d & 7);
-                    if (d < 36) {
-                        const uint32_t idx8 = sft >= 3 ? (fmk[g] >> (sft - 3)) & 0x78u : (fmk[g] << (3 - sft)) & 0x78u;
-                        e[dd] = *reinterpret_cast<lds_cu64>((uint32_t)PK4_OFF + idx8);
-                    }
-                }
-#pragma unroll
-                for (int dd = 0; dd < GRP2; dd++) {
-                    const int d = d0 + dd;
-                    if (d < 36) {
-                        const uint32_t packed = __builtin_amdgcn_perm(0u, c[d], (uint32_t)e[dd]);
-                        const unsigned long long win = (unsigned long long)packed << fill8;
-                        lo |= (uint32_t)win;
-                        fill8 += (uint32_t)(e[dd] >> 32);
-                        const bool full = fill8 >= 32u;
-                        const uint32_t sa = (full || !sparse) ? waddr : dump;
-                        asm volatile("ds_or_b32 %0, %1" ::"v"(sa), "v"(lo) : "memory");
-                        lo = full ? (uint32_t)(win >> 32) : lo;
-                        waddr += full ? 4u : 0u;
-                        fill8 &= 31u;
-                    }
-                }
-            }
-            asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory");
-        }
-#else
         const uint32_t(&fmk_)[5] = fmk;
         auto pass2 = [&](auto sparse_c) {
             constexpr bool SPARSE = decltype(sparse_c)::value;
             // (opaque copies of the masks per instantiation: what the two have in common -- table look-ups, packed dwords -- is otherwise hoisted above
             // the branch and held across it: 118 -> 143 registers)
-            uint32_t fmk[5] = {fmk_[0], fmk_[1], fmk_[2], fmk_[3], fmk_[4]};
+            uint32_t fm[5] = {fmk_[0], fmk_[1], fmk_[2], fmk_[3], fmk_[4]};
 #pragma unroll
-            for (int g = 0; g < 5; g++) asm volatile("" : "+v"(fmk[g]));
+            for (int g = 0; g < 5; g++) asm volatile("" : "+v"(fm[g]));
             uint32_t waddr = (uint32_t)(uintptr_t)(lds_u8 *)D + (base & ~3u); // aligned LDS address of the dword being filled
-            uint32_t fill8 = 8u * (base & 3u), lo = 0;                        // bits of it that belong to the lanes before this one
-            const uint32_t dump = (uint32_t)(uintptr_t)(lds_u8 *)reinterpret_cast<uint8_t *>(&S.list[0]) + 4u * (uint32_t)lane;
-            constexpr int GRP2 = S2K_PASS2_GROUP; // table entries fetched at a time: one LDS round trip per group instead of one per dword
+            uint32_t fill8 = 8u * (base & 3u), lo = 0;                        // bits of it that lie before this lane's next run head; this lane's share of them
+            // (sparse tiles: a dump slot of two dwords, so that "offset:4" works on it as on the buffer; lanes i and i + 32 share one -- nobody reads it)
+            const uint32_t dump = (uint32_t)(uintptr_t)(lds_u8 *)reinterpret_cast<uint8_t *>(&S.list[0]) + 8u * ((uint32_t)lane & 31u);
+            constexpr int GRPQ = 9; // table entries fetched at a time: one LDS round trip per group instead of one per step
 #pragma unroll
-            for (int d0 = 0; d0 < 36; d0 += GRP2) {
-                unsigned long long e[GRP2];
+            for (int q0 = 0; q0 < 18; q0 += GRPQ) {
+                unsigned long long e[GRPQ];
+                uint32_t ix[GRPQ];
 #pragma unroll
-                for (int dd = 0; dd < GRP2; dd++) {
-                    const int d = d0 + dd, g = d >> 3, sft = 4 * (d & 7);
-                    if (d < 36) {
-                        const uint32_t idx8 = sft >= 3 ? (fmk[g] >> (sft - 3)) & 0x78u : (fmk[g] << (3 - sft)) & 0x78u; // 8 x the dword's flag nibble
-                        e[dd] = *reinterpret_cast<lds_cu64>((uint32_t)PK4_OFF + idx8);
-                    }
+                for (int qq = 0; qq < GRPQ; qq++) {
+                    const int q = q0 + qq;
+                    ix[qq] = byte_x8_sel(fm[q >> 2], q & 3); // 8 x the flag byte of raw bytes 8 q .. 8 q + 7 (one SDWA instruction)
+                    e[qq] = *reinterpret_cast<lds_cu64>((uint32_t)SEL8_OFF + ix[qq]);
                 }
 #pragma unroll
-                for (int dd = 0; dd < GRP2; dd++) {
-                    const int d = d0 + dd;
-                    if (d < 36) {
-                        const uint32_t packed = __builtin_amdgcn_perm(0u, c[d], (uint32_t)e[dd]);
-                        const unsigned long long win = (unsigned long long)packed << fill8; // fill8 < 32
-                        lo |= (uint32_t)win;
-                        if constexpr (!SPARSE) asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory");
-                        fill8 += (uint32_t)(e[dd] >> 32);
-                        const bool full = fill8 >= 32u;
-                        if constexpr (SPARSE) {
-                            const uint32_t sa = full ? waddr : dump;
-                            asm volatile("ds_write_b32 %0, %1" ::"v"(sa), "v"(lo) : "memory");
-                        }
-                        lo = full ? (uint32_t)(win >> 32) : lo;
-                        waddr += full ? 4u : 0u;
-                        fill8 &= 31u;
+                for (int qq = 0; qq < GRPQ; qq++) {
+                    const int q = q0 + qq;
+                    const uint32_t plo = __builtin_amdgcn_perm(c[2 * q + 1], c[2 * q], (uint32_t)e[qq]);         // run heads 1-4 of the eight bytes
+                    const uint32_t phi = __builtin_amdgcn_perm(c[2 * q + 1], c[2 * q], (uint32_t)(e[qq] >> 32)); // ... 5-8 (selector 0x0C: a zero byte)
+                    const unsigned long long win = (((unsigned long long)phi << 32) | plo) << fill8;             // fill8 <= 24
+                    const uint32_t w0 = lo | (uint32_t)win, w1 = (uint32_t)(win >> 32);
+                    const uint32_t w2 = (phi >> 8) >> (24u - fill8);           // bits 64 .. of the window: phi >> (32 - fill8), and 0 for fill8 = 0
+                    const uint32_t nb = fill8 + 8u * (uint32_t)__popc(ix[qq]); // <= 88
+                    if constexpr (!SPARSE) {
+                        asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" ::"v"(waddr), "v"(w0), "v"(w1) : "memory");
+                        lo = w2; // (the first two dwords are in place; only what lies beyond them is carried)
+                    } else {
+                        const uint32_t a0 = nb >= 32u ? waddr : dump, a1 = nb >= 64u ? waddr : dump;
+                        asm volatile("ds_write_b32 %0, %2\n\tds_write_b32 %1, %3 offset:4" ::"v"(a0), "v"(a1), "v"(w0), "v"(w1) : "memory");
+                        lo = nb >= 64u ? w2 : (nb >= 32u ? w1 : w0);
                     }
+                    waddr += (nb >> 3) & 0xCu; // 4 x (dwords completed: 0, 1 or 2)
+                    fill8 = nb & 24u;
                 }
             }
-            asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory"); // what the lane holds of a dword it did not complete
+            asm volatile("ds_or_b32 %0, %1" ::"v"(waddr), "v"(lo) : "memory"); // what the lane holds of a dword it did not complete / beyond the last one it OR-ed
         };
+        static_assert(sizeof(S.list) >= 32 * 8, "the dump slots of the sparse variant live in the hit list");
         if (10u * R < 6u * tile_len) pass2(std::true_type{}); // (wave-uniform)
         else pass2(std::false_type{});
-#endif
     }
 #else
     {
@@ -1530,16 +1494,7 @@ __global__ __launch_bounds__(64 * tw<HPC>(), waves_per_simd<HPC>()) void tile_mi
     if constexpr (HPC && S2K_SEL8 != 0)
         for (int c = threadIdx.x; c < 256 * 8; c += 64 * TW) {
             const uint32_t m = (uint32_t)c >> 3, n = (uint32_t)c & 7u;
-            smem[SEL8_OFF + c] = (uint8_t)(n < (uint32_t)__popc(m) ? select_nth_32(m, n) : 0u);
-        }
-    if constexpr (HPC && S2K_PASS2_ACC != 0)
-        if (threadIdx.x < 16) {
-            const uint32_t n = threadIdx.x;
-            uint32_t sel = 0, j = 0;
-            for (uint32_t b = 0; b < 4; b++)
-                if ((n >> b) & 1u) sel |= b << (8 * j++); // byte j of the result = byte b of the dword (v_perm_b32: 0..3 = bytes of the second source)
-            for (; j < 4; j++) sel |= 0x0Cu << (8 * j);   // ... 0x0C = the constant 0x00
-            reinterpret_cast<uint2 *>(smem + PK4_OFF)[n] = make_uint2(sel, 8u * (uint32_t)__popc(n));
+            smem[SEL8_OFF + c] = (uint8_t)(n < (uint32_t)__popc(m) ? select_nth_32(m, n) : 0x0Cu); // (0x0C: as a v_perm_b32 selector byte, "zero" -- the table is pass 2's too)
         }
     __syncthreads(); // the only workgroup barrier; waves are independent from here on
 #ifdef S2K_DEBUG_KNOBS
