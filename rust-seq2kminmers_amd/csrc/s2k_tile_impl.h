@@ -603,7 +603,7 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     const uint32_t last_raw = bcast(c[35] >> 24, 63); // last raw byte of a full tile
     // the 128 staged look-ahead bytes serve the first round of the run-head search after the tile; read them
     // before the buffer is compacted in place (lanes 0..31, 4 bytes each)
-    const uint32_t la_word = lane < 32 ? *reinterpret_cast<const uint32_t *>(D + TILE_BASES + 4 * lane) : 0u;
+    const uint32_t la_a = D[TILE_BASES + lane], la_b = D[TILE_BASES + 64 + lane]; // (one byte per lane and round)
     const int vb = (int)tile_len - (int)lane_off;      // valid bytes in this lane's chunk (may be <=0 or >=144)
     const bool partial = tile_len < (uint32_t)TILE_BASES;
     // 3. pass 1: SWAR "differs from its predecessor" per byte -> four flags per dword -> natural-order masks
@@ -767,21 +767,36 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
     const uint32_t hl = sem.tail_quirk ? l + 16 : l;
     uint32_t halo_n = 0;
     if (!partial) {
-        uint64_t q = t0 + TILE_BASES;
         uint32_t pb = last_raw;
-        bool first = true;
-        while (halo_n < hl && q < n_bases) { // wave-uniform
-            const uint32_t span = first ? 128u : 256u; // bytes examined this round
-            uint64_t a = q + 4 * (uint64_t)lane;
-            int nval = (a >= n_bases || 4u * (uint32_t)lane >= span) ? 0 : (n_bases - a >= 4 ? 4 : (int)(n_bases - a));
-            uint32_t wv = 0;
-            if (first) {
-                wv = la_word; // bytes past the end of the stream were staged as zeros and are masked by nval
-            } else {
-                if (nval == 4) wv = *reinterpret_cast<const uint32_t *>(bases + a);
-                else
-                    for (int b = 0; b < nval; b++) wv |= (uint32_t)bases[a + b] << (8 * b);
+        // the staged look-ahead first, ONE BYTE PER LANE and round of 64 bytes: a run head is a byte that differs from the lane before's (DPP), its index
+        // among the heads one ballot and a bit count away -- a dozen instructions per round, one round as a rule (uniform ACGT: 48 run heads in 64 bytes;
+        // rounds 1-4 looked at four bytes per lane with a wave scan and four guarded stores: ~65 + 30 scalar)
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const uint64_t qr = t0 + TILE_BASES + 64 * rnd;
+            if (halo_n >= hl || qr >= n_bases) break; // wave-uniform
+            const uint32_t by = rnd ? la_b : la_a;
+            const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp((int)pb, (int)by, 0x138, 0xf, 0xf, false); // wave_shr:1 -- lane 0 keeps pb, the byte before the round
+            const bool hd = qr + (uint64_t)lane < n_bases && by != pv; // (bytes past the end of the stream were staged as zeros: masked here)
+            const uint64_t mk = __ballot(hd);
+            const uint32_t idx = halo_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (hd && idx < hl) {
+                D[R + idx] = (uint8_t)by;
+                S.halo_pos[idx] = (uint32_t)(TILE_BASES + 64 * rnd) + (uint32_t)lane;
             }
+            halo_n += (uint32_t)__popcll(mk);
+            pb = bcast(by, 63);
+        }
+        // ... then the stream itself, 256 bytes per round (long homopolymers, sparse run heads)
+        uint64_t q = t0 + TILE_BASES + 128;
+        while (halo_n < hl && q < n_bases) { // wave-uniform
+            const uint32_t span = 256u; // bytes examined this round
+            uint64_t a = q + 4 * (uint64_t)lane;
+            int nval = a >= n_bases ? 0 : (n_bases - a >= 4 ? 4 : (int)(n_bases - a));
+            uint32_t wv = 0;
+            if (nval == 4) wv = *reinterpret_cast<const uint32_t *>(bases + a);
+            else
+                for (int b = 0; b < nval; b++) wv |= (uint32_t)bases[a + b] << (8 * b);
             uint32_t pw = __shfl_up(wv, 1);
             if (lane == 0) pw = pb << 24;
             uint32_t prv = (wv << 8) | (pw >> 24);
@@ -802,9 +817,8 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
                 }
             }
             halo_n += bcast(in2, 63);
-            pb = bcast(wv >> 24, first ? 31 : 63);
+            pb = bcast(wv >> 24, 63);
             q += span;
-            first = false;
         }
         if (halo_n > hl) halo_n = hl;
     }
