@@ -15,8 +15,9 @@ def test_counted_vmcnt_wait_matches_the_emitted_stores():
 
 
 def test_tiled_kernels_fit_their_waves_per_simd_without_scratch():
-    """The persistent tile kernel runs one block per CU: 12 waves = three per SIMD for Hpc (512 VGPRs / 3 = 168 per wave at most), 16 = four per
-    SIMD for the Regular family (128), and no
+    """The persistent tile kernel runs one block per CU: 12 waves = three per SIMD for Hpc -- 512 VGPRs / 3 = 168 per wave by its own occupancy, but the
+    k-min-mer kernel's waves (57 VGPRs) run BESIDE it and need the rest: at 159 the step was 11 % slower (profiles/r05_ab_args_in_vgprs.txt), so its budget is
+    128 --, 16 = four per SIMD for the Regular family (128), and no
     scratch (a spill in the hash loop costs more than anything else in it).  Round 3 lost 20-55 VGPRs to loop-invariant lane
     arithmetic hoisted across the hash loop; this keeps that from coming back unnoticed.  Also: the compile-time-l
     kernels use gfx950's three-input bit operation in the hash loop (2 x 144 positions x 2 strands and more)."""
@@ -31,9 +32,8 @@ def test_tiled_kernels_fit_their_waves_per_simd_without_scratch():
         for m in re.finditer(r"\.name:\s+(\S*tile_minimizer_kernel\S*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text):
             kern, vgprs, spills = m.group(1), int(m.group(2)), int(m.group(3))
             seen += 1
-            # Hpc kernels: three waves per SIMD (<= 168 registers); Regular family: FOUR (16-wave blocks): <= 128
-            hpc = "ELb1ELb" in kern.split("tile_minimizer_kernelILi")[1][:12]
-            assert vgprs <= (168 if hpc else 128), (name, kern, vgprs)
+            # Hpc kernels: three waves per SIMD and two k-min-mer waves beside them; Regular family: four waves per SIMD (16-wave blocks): <= 128 either way
+            assert vgprs <= 128, (name, kern, vgprs)
             assert spills == 0, (name, kern, spills)
         for m in re.finditer(r"; ScratchSize: (\d+)", text):
             assert int(m.group(1)) == 0, (name, "scratch", m.group(1))
