@@ -256,7 +256,19 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
     // ---- round trip 2: the up to k-1 minimizers of the continuing read that lie before the tile (lane q: the (q+1)-th counted
     //      backwards) = the last records of the tiles before this one; a tile that is one stretch of the read hands on to the tile
     //      before it.  The counts of the 63 tiles before this one are in the lanes already.
-    if (p_in) { // wave-uniform
+    // (the tile before holds all of them as a rule -- it has ~140 minimizers, k - 1 are wanted: then no counts are scanned and nothing is searched)
+    const uint32_t N1 = (dk_lane((uint32_t)agw, 1) >> 28 | dk_lane((uint32_t)(agw >> 32), 1) << 4) & 0x3FFFu; // minimizers of tile t - 1 (0 before tile 0)
+    if (p_in && N1 >= p_in) { // wave-uniform
+        if ((uint32_t)lane < p_in) {
+            const uint32_t q = (uint32_t)lane, idx = N1 - 1u - q;
+            const uint64_t u = t - 1; // (p_in > 0: a read continues into the tile, so there is a tile before it)
+            const uint64_t bu = N1 <= rec.slab_cap ? slab - rec.slab_cap : dz.meta[u].rec_base;
+            const uint32_t pos = rec.j[bu + idx];
+            s_ring[w][K1 - 1 - q] = mix32(rec.hash[bu + idx]);
+            s_jcar[w][K1 - 1 - q] = (uint32_t)(u * (uint64_t)TILE_BASES + (pos & 0x3FFFu) - rs0); // the same read: it starts at rs0
+        }
+        wave_sync();
+    } else if (p_in) { // wave-uniform
         const uint32_t Nl = lane >= 1 ? (uint32_t)((agw >> 28) & 0x3FFFu) : 0u; // lane i >= 1: minimizers of tile t - i
         s_cum_w[lane] = dk_incl_scan(Nl);                                        // ... of tiles t-1 .. t-i together
         wave_sync();

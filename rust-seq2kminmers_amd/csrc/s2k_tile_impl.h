@@ -96,7 +96,7 @@ constexpr int MAX_L_TILED = 64;
 #define S2K_JOBCAP 32
 #endif
 #ifndef S2K_REDERIVE_GROUP
-#define S2K_REDERIVE_GROUP 4 // bases a lane of a re-derivation quad fetches at a time (8 = all of them at once: measured equal, profiles/r05_ab_rederive.txt)
+#define S2K_REDERIVE_GROUP 8 // bases a lane of a re-derivation quad fetches at a time (8 = all of them at once; 4: +0.2 % kernel time, profiles/r05_ab_knobs_steady.txt)
 #endif
 constexpr int LISTCAP_REG = S2K_TW_REG > 12 ? 216 : S2K_LISTCAP; // hits handled per dense batch (Regular: 184 +- 13 per tile; 216 = what 16 waves' LDS leaves)
 constexpr int LISTCAP_HPC = 192;                                      // ... Hpc: 137 +- 11 per tile of uniform ACGT; the 128 bytes pay for the wider rows of the back-map
@@ -231,11 +231,11 @@ __device__ __forceinline__ uint32_t div_tq(uint32_t x, uint32_t rcp) { return __
 // x / TILE_T for x < 20 000 (a tile-relative offset): one 24-bit multiply and a shift (3641 / 2^19 = 1 / 144.0002; checked for every x below 20 000)
 static_assert(TILE_T == 144, "div_tile_t's reciprocal is that of 144");
 __device__ __forceinline__ uint32_t div_tile_t(uint32_t x) { return __umul24(x, 3641u) >> 19; }
-// bits [0, v) of a word: none for v <= 0, all for v >= 32 (v_med3_i32, v_bfm_b32, compare, select)
+// bits [0, v) of a word: none for v <= 0, all for v >= 32: v_med3_i32, a 64-bit shift (1 << 32 leaves a zero low word) and a decrement -- three instructions
+// (rounds 2-5 selected between a 32-bit shift's result and all ones: five; the dense phase forms fifteen of these masks per tile)
 __device__ __forceinline__ uint32_t bits_below(int v) {
     const int t = v < 0 ? 0 : (v > 32 ? 32 : v);
-    const uint32_t m = (1u << ((uint32_t)t & 31u)) - 1u;
-    return t == 32 ? 0xFFFFFFFFu : m;
+    return (uint32_t)(1ull << (uint32_t)t) - 1u;
 }
 // heads of a raw lane before its flag word g (0 .. 4), from the lane's cum word (byte k = heads in words 0 .. k): byte g - 1, or 0 for g = 0 --
 // one v_perm_b32 whose selector picks a zero byte for g = 0
@@ -590,9 +590,13 @@ __device__ __forceinline__ uint32_t hpc_compact(uint8_t *D, WL &S, const uint8_t
         uint4 v = src[p];
         c[4 * p] = v.x; c[4 * p + 1] = v.y; c[4 * p + 2] = v.z; c[4 * p + 3] = v.w;
     }
-    uint32_t fmk[5];
-#pragma unroll
-    for (int g = 0; g < 5; g++) fmk[g] = S.row[lane][g]; // forced heads
+    uint32_t fmk[5]; // forced heads
+    {
+        const uint2 *rr = reinterpret_cast<const uint2 *>(&S.row[lane][0]);
+        const uint2 r01 = rr[0], r23 = rr[1];
+        fmk[0] = r01.x; fmk[1] = r01.y; fmk[2] = r23.x; fmk[3] = r23.y;
+        fmk[4] = S.row[lane][4];
+    }
     uint32_t prevw;
     if (lane == 0) {
         if (forced0) fmk[0] |= 1u; // the tile starts a read
@@ -974,7 +978,7 @@ template <int L, bool HPC, bool DESC, class WL, class IssueNext>
 __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, const uint8_t *D, const uint2 *tab,
                                                 const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t t,
                                                 uint64_t t0, uint32_t tile_len, uint32_t nh, uint32_t halo_n,
-                                                uint32_t Tq, uint32_t l, uint32_t r0, uint32_t r1, uint64_t bpos0,
+                                                uint32_t Tq, uint32_t rcpTq, uint32_t l, uint32_t r0, uint32_t r1, uint64_t bpos0,
                                                 uint64_t rs0, int lane, const Records &rec, uint64_t *pool_cursor,
                                                 uint32_t *mn_cnt, Counts *counts, uint64_t &base, const Sem &sem,
                                                 unsigned long long *__restrict__ d_agg, TileMeta *__restrict__ d_meta, uint32_t K1,
@@ -987,7 +991,7 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     //     end of the stream) is the one external boundary.
     constexpr int LISTCAP = listcap<HPC>();
     const uint32_t wclr = HPC ? (sem.keep_last ? l - 1 : l) : l - 1; // Hpc drops the last l-mer of a read (src/nthash_hpc.rs:265-267)
-    const uint32_t rcpTq = Tq == 112u ? 9363u : Tq == 48u ? 21846u : Tq == 80u ? 13108u : Tq == 144u ? 7282u : 65537u; // 65536 / (Tq / 16) + 1 for Tq / 16 in {7, 3, 5, 9, 1}: see div_tq (a division costs ~25 instructions per tile)
+    // rcpTq = 65536 / (Tq / 16) + 1 for Tq / 16 in {7, 3, 5, 9, 1}: see div_tq (a division costs ~25 instructions per tile); chosen by the kernel together with Tq
     const uint32_t tql = __umul24(Tq, (uint32_t)lane); // first hash position of this lane
     uint32_t vm[5]; // validated hit mask of this lane
     {
@@ -1114,17 +1118,9 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
                 const int wz = (int)wclr + (int)bcast(wextra, z);
                 if (hbz - wz >= (int)nh) continue; // (wave-uniform: the next read starts so far behind the tile that the range holds none of its positions -- most tiles)
                 const int lo = hbz - wz - (int)tql, hi = hbz - 1 - (int)tql; // lane-local, inclusive
-                if (hi >= 0 && lo < (int)Tq) {
+                // (branch-free: seven instructions per word for every lane; guarded per lane and per word it was a dozen each plus the exec-mask traffic)
 #pragma unroll
-                    for (int d = 0; d < 5; d++) {
-                        const int a = lo - 32 * d, bnd = hi - 32 * d;
-                        if (bnd >= 0 && a < 32) {
-                            const uint32_t m_hi = bnd >= 31 ? 0xFFFFFFFFu : ((2u << bnd) - 1u);
-                            const uint32_t m_lo = a <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << a);
-                            vm[d] &= ~(m_hi & m_lo);
-                        }
-                    }
-                }
+                for (int d = 0; d < 5; d++) vm[d] &= ~(bits_below(hi + 1 - 32 * d) & ~bits_below(lo - 32 * d));
             }
             if constexpr (!HPC) {
                 // A read of exactly l bases has one l-mer that fits, but the reference yields nothing unless
@@ -1699,9 +1695,11 @@ __global__ __launch_bounds__(64 * tw<HPC>(), waves_per_simd<HPC>()) void tile_mi
             }
         }
         if (lane == 0) S.buf[HS_OFF - 1] = 0;
-        if constexpr (HPC) {
-#pragma unroll
-            for (int g2 = 0; g2 < 5; g2++) S.row[lane][g2] = 0; // read-start marks are OR-ed in by hpc_compact
+        if constexpr (HPC) { // read-start marks are OR-ed in by hpc_compact (a row is 24 bytes: 8-byte stores)
+            uint2 *rz = reinterpret_cast<uint2 *>(&S.row[lane][0]);
+            rz[0] = make_uint2(0u, 0u);
+            rz[1] = make_uint2(0u, 0u);
+            S.row[lane][4] = 0;
         }
         wave_sync();
         S2K_STAMP(0); // staging
@@ -1710,6 +1708,7 @@ __global__ __launch_bounds__(64 * tw<HPC>(), waves_per_simd<HPC>()) void tile_mi
         uint32_t lb_early = 0;  // (HpcSimd) early look at the words of the tiles before this one, see below
         uint32_t halo_n = 0;
         int np = 9;
+        uint32_t rcpTq = 7282u; // 65536 / 9 + 1
         if constexpr (HPC) {
 #ifndef EXP_NOCOMPACT
             if (!(sem.dbg_skip & 4))
@@ -1732,8 +1731,9 @@ __global__ __launch_bounds__(64 * tw<HPC>(), waves_per_simd<HPC>()) void tile_mi
                 if (!(t0 == 0 || rs0 == t0) && t >= 1 + (uint64_t)lane)
                     lb_early = __hip_atomic_load(sem.tile_heads + (t - 1 - (uint64_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            int need = (int)((nh + 1023) >> 10);
+            const int need = (int)((nh + 1023) >> 10);
             np = need <= 1 ? 1 : need <= 3 ? 3 : need <= 5 ? 5 : need <= 7 ? 7 : 9;
+            rcpTq = need <= 1 ? 65537u : need <= 3 ? 21846u : need <= 5 ? 13108u : need <= 7 ? 9363u : 7282u; // 65536 / np + 1 (div_tq)
         }
         S2K_STAMP(1); // hpc compaction
         // ---- the next tile's bases: DMA into this wave's buffer, issued from inside the dense phase (see issue_once) -----
@@ -1821,7 +1821,7 @@ __global__ __launch_bounds__(64 * tw<HPC>(), waves_per_simd<HPC>()) void tile_mi
         if (DESC || (nh != 0 && sem.enabled)) { // (descriptor path: every tile leaves its word and its segment list, hits or not)
 #ifndef EXP_NODENSE
             if (!(sem.dbg_skip & 2))
-                N = dense_phase<L, HPC, DESC>(issue_once, S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, l, cr0, cr1,
+                N = dense_phase<L, HPC, DESC>(issue_once, S, D, tab, read_off, n_reads, t, t0, tile_len, nh, halo_n, Tq, rcpTq, l, cr0, cr1,
                                            bpos0, rs0, lane_d, rec, pool_cursor, mn_cnt, counts, base, sem, d_agg, d_meta, K1,
                                            caps, raw, lb_early, lb_dead, ph, stamp);
 #endif
