@@ -137,7 +137,8 @@ s2k_status s2k_set_stream(s2k_ctx *ctx, void *hip_stream);
  * kernels of b's calls wait for the minimizer kernels of a's most recent call, nothing else does -- so the tail of a's call (its last
  * k-min-mer kernel, the totals, the host's look at the counts) runs beside the first chunk of b's, and two persistent kernels never compete
  * for the device.  Chain both ways (a after b, b after a) and alternate the calls from ONE host thread.  prev = NULL removes the link;
- * s2k_destroy(prev) removes every link to prev by itself (the survivor then runs unchained).  Results do not depend on it. */
+ * s2k_destroy(prev) removes every link to prev by itself (the survivor then runs unchained), from any thread: links are read and cut under one
+ * lock.  A prev that is not a live context is refused (S2K_ERR_INVALID_ARG).  Results do not depend on it. */
 s2k_status s2k_chain_after(s2k_ctx *ctx, s2k_ctx *prev);
 /* s2k_extract cuts a call into sub-batches of whole reads of about `bases` bases each (default 2^29; 0 restores it) and
  * pipelines them: H2D of one, kernels of the previous, D2H of the one before run side by side.  Results do not depend

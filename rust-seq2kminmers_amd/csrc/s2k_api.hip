@@ -360,7 +360,12 @@ s2k_status enqueue(s2k_ctx *ctx) {
         // ~1.7 Gbp (10 Gbp: six 6.35-6.41, three 6.48-6.51), either way between two and eight.  (Rounds 3-4 used fixed counts: 6, and 2 for chained calls.)
         // Regular family: its minimizer kernel runs 16 waves per CU and leaves the k-min-mer kernel no room beside it (s2k_tile_impl.h: tw()): one
         // launch of each, the k-min-mer stage behind the minimizer kernel on the caller's stream
-        uint32_t by_size = (uint32_t)((double)n_bases / (ctx->chain_prev ? 4.0e9 : 1.7e9) + 0.5);
+        bool chained;
+        { // (the link is another context's to cut -- s2k_destroy(prev) on any thread --: looked at under the registry's lock, here and at the wait below)
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            chained = ctx->chain_prev != nullptr;
+        }
+        uint32_t by_size = (uint32_t)((double)n_bases / (chained ? 4.0e9 : 1.7e9) + 0.5);
         by_size = by_size < 2u ? 2u : (by_size > 8u ? 8u : by_size);
         n_chunks = ctx->desc_chunks ? ctx->desc_chunks : (c.sem.hpc ? by_size : 1u);
         const uint64_t min_chunk = ctx->desc_chunks ? 64 : 12 * 3072; // tiles: a dozen per resident wave (a forced count -- tests -- only needs 64)
@@ -456,7 +461,13 @@ s2k_status enqueue(s2k_ctx *ctx) {
                 "read table kernel");
         // s2k_chain_after: this call's minimizer kernels start when those of the other context's call have ended (the launches above
         // -- a memset, the read table -- need not wait)
-        if (ctx->chain_prev && ctx->chain_prev->tiles_done_valid) S2K_TRY(hipStreamWaitEvent(st, ctx->chain_prev->tiles_done, 0), "stream wait (chain)");
+        // (under the registry's lock: s2k_destroy(prev) cuts the link under the same lock BEFORE it destroys the event, so the wait is either enqueued
+        // on a live event or not at all)
+        {
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            s2k_ctx *const prev = ctx->chain_prev;
+            if (prev && prev->tiles_done_valid) S2K_TRY(hipStreamWaitEvent(st, prev->tiles_done, 0), "stream wait (chain)");
+        }
         if (!ctx->tiles_done) S2K_TRY(hipEventCreateWithFlags(&ctx->tiles_done, hipEventDisableTiming), "event create");
         Sem sem = c.sem;
         sem.read_runs = nullptr;
@@ -805,7 +816,12 @@ s2k_status s2k_set_stream(s2k_ctx *ctx, void *hip_stream) {
 
 s2k_status s2k_chain_after(s2k_ctx *ctx, s2k_ctx *prev) {
     if (!ctx || prev == ctx) return S2K_ERR_INVALID_ARG;
-    if (prev && prev->device != ctx->device) return S2K_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (prev) { // a context that is not (or no longer) alive cannot be chained to
+        bool live = false;
+        for (s2k_ctx *c : g_live_ctx) live = live || c == prev;
+        if (!live || prev->device != ctx->device) return S2K_ERR_INVALID_ARG;
+    }
     ctx->chain_prev = prev;
     return S2K_OK;
 }

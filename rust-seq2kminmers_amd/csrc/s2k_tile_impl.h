@@ -71,7 +71,11 @@ namespace {
 #define S2K_TW 12
 #endif
 #ifndef S2K_TW_REG
+#ifdef S2K_PROFILE
+#define S2K_TW_REG 12 // PROFILE builds: the phase accumulators need 2 KiB of LDS, and 16 Regular waves use all 160 KiB -- the Regular family is profiled at three waves per SIMD
+#else
 #define S2K_TW_REG 16
+#endif
 #endif
 // waves per block = all the waves of a CU: ONE block per CU shares the seed tables.  Hpc: 12 = three per SIMD (12 KB of LDS per wave: the rows of the
 // back-map beside the tile buffer), and the k-min-mer kernel's blocks run BESIDE it in what is left of the CU.  Regular family (Regular, Simd): 16 = four

@@ -36,7 +36,8 @@ def test_two_ranks_equal_unsharded(tmp_path):
     assert two["config"]["reads_total"] == 6000 and 1.0 <= two["config"]["largest_shard_over_mean"] < 1.01
     assert one["verified_vs_oracle"] and two["verified_vs_oracle"]
     # the JSON proves how many ranks the process group saw, and the one real exchange step (count: all-to-all by hash prefix) ran
-    assert one.get("collective") is None and two["collective"]["world_size_seen"] == 2  # (a leg that did not run leaves no key in the line) and two["collective"]["ranks"] == [0, 1]
+    # (a leg that did not run leaves no key in the line)
+    assert one.get("collective") is None and two["collective"]["world_size_seen"] == 2 and two["collective"]["ranks"] == [0, 1]
     assert two["per_rank"]["wall_ms_per_step_max"] >= two["per_rank"]["wall_ms_per_step_min"] > 0
     assert one.get("downstream_count") is None and two["downstream_count"]["n_keys"] == two["counts"]["kminmers"]
     assert two["downstream_count"]["exchange"].startswith("all_to_all_single")

@@ -40,3 +40,23 @@ def test_tiled_kernels_fit_their_waves_per_simd_without_scratch():
         if name == "s2k_tile_L31.s":
             assert text.count("bitop3:0x96") >= 4 * 2 * 144, "v_bitop3_b32 (three-input XOR) missing from the hash loop"
     assert seen >= 8, seen  # 4 instantiations (Hpc / Regular x descriptor / legacy) per translation unit
+
+
+def test_profile_and_knobs_configurations_still_compile():
+    """`make PROFILE=1` / `make KNOBS=1` are what tools/phases.sh and tools/ab/*.sh build on the GPU box; a static_assert that only
+    fires in those configurations (round 5: the PROFILE accumulators pushed the Regular block over 160 KiB of LDS) would go unnoticed
+    until a GPU call is spent on it.  Syntax-only, host + device passes, a few seconds each."""
+    csrc = os.path.join(ROOT, "rust-seq2kminmers_amd", "csrc")
+    for flags in (["-DS2K_PROFILE", "-DS2K_DEBUG_KNOBS"], ["-DS2K_DEBUG_KNOBS"]):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", *flags, "s2k_tile.hip"],
+                           cwd=csrc, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (flags, r.stderr[-3000:])
+
+
+def test_experiment_benches_still_compile():
+    """tools/experiments/hash_loop_bench.hip and hash_stream_bench.hip include the kernel's own header (profiles/README cites them as
+    reproducible evidence): they must keep compiling against it."""
+    for src in ("hash_loop_bench.hip", "hash_stream_bench.hip"):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", "-I", "rust-seq2kminmers_amd/csrc",
+                            os.path.join("tools", "experiments", src)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (src, r.stderr[-3000:])

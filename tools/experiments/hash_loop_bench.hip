@@ -8,6 +8,11 @@
 #include <vector>
 
 using namespace s2k;
+// (TW / S2K_WAVES_PER_SIMD left s2k_tile_impl.h in round 5 -- tw<HPC>() / waves_per_simd<HPC>() --: the bench keeps its own, -DS2K_TW=<waves per block>)
+constexpr int TW = S2K_TW;
+#ifndef S2K_WAVES_PER_SIMD
+#define S2K_WAVES_PER_SIMD ((S2K_TW + 3) / 4)
+#endif
 #ifndef HX_BPC
 #define HX_BPC 1 // blocks per CU (more than 16 waves per CU need more than one block)
 #endif

@@ -9,6 +9,7 @@
 #include <vector>
 
 using namespace s2k;
+constexpr int TW = S2K_TW; // (left s2k_tile_impl.h in round 5: tw<HPC>())
 #ifndef HS_BPC
 #define HS_BPC 1
 #endif
