@@ -351,6 +351,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
     // chunk c run on a second stream (they need ~1/6 of the time and, being bound by latency, fit beside a kernel that leaves
     // a quarter of the issue slots and some LDS free).  A chunk is at least a few tiles per resident wave.
     uint32_t n_chunks = 1;
+    bool chained = false; // this context's calls are chained behind another's (s2k_chain_after)
     if (use_desc) {
         // Hpc, how many chunks: more chunks = a smaller exposed tail (the last chunk's k-min-mer kernel, alone on the device) and chunks whose records are
         // still near when their k-min-mer kernel reads them; fewer = fewer chunk boundaries (~40 us each: waves run dry, a launch, a first tile's unhidden load).
@@ -360,7 +361,6 @@ s2k_status enqueue(s2k_ctx *ctx) {
         // ~1.7 Gbp (10 Gbp: six 6.35-6.41, three 6.48-6.51), either way between two and eight.  (Rounds 3-4 used fixed counts: 6, and 2 for chained calls.)
         // Regular family: its minimizer kernel runs 16 waves per CU and leaves the k-min-mer kernel no room beside it (s2k_tile_impl.h: tw()): one
         // launch of each, the k-min-mer stage behind the minimizer kernel on the caller's stream
-        bool chained;
         { // (the link is another context's to cut -- s2k_destroy(prev) on any thread --: looked at under the registry's lock, here and at the wait below)
             std::lock_guard<std::mutex> lk(g_ctx_mu);
             chained = ctx->chain_prev != nullptr;
@@ -406,8 +406,8 @@ s2k_status enqueue(s2k_ctx *ctx) {
             d_scan = a.take<unsigned long long>(desc_scan_tmp_words(n_tiles));
         }
         const uint64_t rec_total = c.serial ? c.pool_cap : n_tiles * c.slab_cap + c.pool_cap;
-        rec.j = a.take<uint32_t>(rec_total);
-        rec.hash = a.take<uint32_t>(rec_total);
+        rec.j = a.take<uint32_t>(rec_total + 4); // (+4: the k-min-mer kernel's lanes fetch up to four consecutive records at a time, the last lane past the tile's count)
+        rec.hash = a.take<uint32_t>(rec_total + 4);
         rec.jend = use_desc ? nullptr : a.take<uint32_t>(rec_total); // (descriptor path: rec.j holds {offset in the tile, span})
         rec.rid = use_desc ? nullptr : a.take<uint32_t>(rec_total);
         rec.capacity = rec_total;
@@ -513,7 +513,9 @@ s2k_status enqueue(s2k_ctx *ctx) {
                 if (tm) S2K_TRY(hipEventRecord(ctx->ev[2], st), "event");
                 if (tm) S2K_TRY(hipEventRecord(ctx->ev[3], st), "event");
                 S2K_TRY(launch_desc_scan(0, n_tiles, dz, d_scan, ctx->d_counts, st), "tile word scan");
-                S2K_TRY(launch_desc_kminmers(0, n_tiles, n_tiles, n_reads, dz, rec, ctx->d_counts, st), "k-min-mer kernel");
+                // (alone: the Regular family's minimizer kernel -- this context's or a chained one's -- uses the whole LDS of a CU: none of its blocks is ever
+                // resident beside a block of this kernel, whatever that one's size)
+                S2K_TRY(launch_desc_kminmers(0, n_tiles, n_tiles, n_reads, dz, rec, ctx->d_counts, st, true), "k-min-mer kernel");
                 if (tm) S2K_TRY(hipEventRecord(ctx->ev[4], st), "event");
             } else {
                 // fork: the second stream starts behind everything that is in the caller's stream so far
@@ -553,7 +555,9 @@ s2k_status enqueue(s2k_ctx *ctx) {
                     if (nokm) continue;
 #endif
                     S2K_TRY(launch_desc_scan(T0, T1, dz, d_scan, ctx->d_counts, s2), "tile word scan");
-                    S2K_TRY(launch_desc_kminmers(T0, T1, n_tiles, n_reads, dz, rec, ctx->d_counts, s2), "k-min-mer kernel");
+                    // (the last chunk's k-min-mer kernel has the device to itself unless a chained context's next call follows)
+                    static const bool tail_coal = getenv("S2K_KM_TAIL_COAL") != nullptr;
+                    S2K_TRY(launch_desc_kminmers(T0, T1, n_tiles, n_reads, dz, rec, ctx->d_counts, s2, tail_coal && ch + 1 == n_chunks && !chained), "k-min-mer kernel");
                 }
                 S2K_TRY(hipEventRecord(ctx->tiles_done, st), "event");
                 ctx->tiles_done_valid = true;

@@ -12,6 +12,7 @@
 //     starts; km_off (and mn_off) of the reads that start in the tile are written here too.  No per-read table is read.
 #include "s2k_dev.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace s2k {
 namespace {
@@ -187,13 +188,19 @@ __device__ inline uint32_t dk_lane(uint32_t v, int src) { return (uint32_t)__bui
 // KT: compile-time k (the window loop is unrolled and reads the ring at constant offsets), or 0: run-time k <= 32
 // FULL: the caller wants all four k-min-mer arrays and no minimizer triples (the common call): no per-array tests in the round loop, and a tile whose
 // windows all fit the arrays' capacity (every tile of a call that fits) stores at 32-bit offsets from per-tile scalar bases without a per-lane test
-template <int KT, bool FULL>
-__global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t tile_begin, uint64_t tile_end, uint64_t n_tiles, uint64_t n_reads, Desc dz,
+// COAL (compile-time k, FULL): the kernel has the CU to itself (the Regular family's k-min-mer stage runs BEHIND its minimizer kernel) and LDS to spare: a
+// lane's consecutive windows go through a per-wave staging area so that every store instruction writes 64 CONSECUTIVE windows (whole 128-byte lines per
+// array).  Without it a lane writes its RB windows side by side and a store instruction touches RB times as many lines, each only partly: beside the
+// persistent Hpc kernel (where there is no LDS for the area) that is hidden, alone it made the kernel 20 % slower than the one-window-per-lane rounds
+// (profiles/r06_ab_km1.txt).
+constexpr int DK_STAGE_RECS = 192, DK_STAGE_BYTES = DK_STAGE_RECS * 20; // per wave: {hash, start, end} 16 B + {window index | rev << 31} 4 B per minimizer of a batch
+template <int KT, bool FULL, bool COAL = false>
+__global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kernel(uint64_t tile_begin, uint64_t tile_end, uint64_t n_tiles, uint64_t n_reads, Desc dz,
                                                                         Records rec, Counts *counts) {
-    __shared__ unsigned long long s_ring[DK_WAVES][64 + DK_KMAX];
-    __shared__ unsigned long long s_rs[DK_WAVES][META_SEGS];
-    __shared__ int32_t s_adj[DK_WAVES][META_SEGS];
-    __shared__ uint32_t s_segb[DK_WAVES][META_SEGS];
+    // compile-time k (lane-serial windows, below): the ring only carries the k-1 minimizers before a batch (+ the 64 counts of the slow look-back, which
+    // share its upper entries); run-time k: a round's 64 mixed hashes behind them
+    __shared__ unsigned long long s_ring[DK_WAVES][(KT > 0 ? 32 : 64) + DK_KMAX];
+    __shared__ uint4 s_seg[DK_WAVES][META_SEGS]; // per read segment of the tile: {hits before it, hit index -> window index, (tile start - read start) mod 2^32, -}
     __shared__ uint32_t s_jcar[DK_WAVES][DK_KMAX];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: per-tile values are scalar
     // cumulative minimizer counts of the 63 tiles before this one (round trip 2 only): they share the ring's upper 64 entries, which the rounds
@@ -233,11 +240,8 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
     const uint32_t wseg = (uint32_t)lane <= nb && mine > skip ? mine - skip : 0u;
     const uint32_t winc = dk_incl_scan(wseg);
     const uint32_t Wb = winc - wseg, Wt = dk_lane(winc, 63);
-    if ((uint32_t)lane <= nb) {
-        s_segb[w][lane] = segstart;
-        s_adj[w][lane] = (int32_t)Wb - (int32_t)segstart - (int32_t)skip;
-        s_rs[w][lane] = lane ? t0 + rs16 : rs0;
-    }
+    if ((uint32_t)lane <= nb) // (read-relative positions are 32-bit: only the low word of tile start - read start is ever needed)
+        s_seg[w][lane] = make_uint4(segstart, (uint32_t)((int32_t)Wb - (int32_t)segstart - (int32_t)skip), lane ? 0u - rs16 : (uint32_t)(t0 - rs0), 0u);
     // km_off / mn_off of the reads that start in (t0, end of the tile]: the first nb inside, the rest exactly at the end
     if (lane >= 1 && (uint32_t)lane <= nrd) {
         dz.o_km_off[(uint64_t)r0 + lane] = (uint32_t)lane <= nb ? G + Wb : G + Wt;
@@ -308,7 +312,6 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
         }
         wave_sync();
     }
-    uint32_t jprev = p_in && (uint32_t)lane >= 64u - K1 ? s_jcar[w][lane - (64u - K1)] : 0u; // "the round before the first": the k-1 minimizers before the tile
     uint64_t xacc = 0;
     // one or two read starts per tile as a rule: their hit indices as scalars (a segment that does not exist starts "never"), no LDS walk per round
     const uint32_t sb1 = nb >= 1u ? dk_lane(segstart, 1) : 0xFFFFFFFFu, sb2 = nb >= 2u ? dk_lane(segstart, 2) : 0xFFFFFFFFu;
@@ -317,6 +320,221 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
     unsigned long long *const t_hash = dz.o_hash + G;
     uint32_t *const t_start = dz.o_start + G, *const t_end = dz.o_end + G;
     uint8_t *const t_rev = dz.o_rev + G;
+    if constexpr (KFIX) {
+    // ---- compile-time k: LANE-SERIAL windows (round 6).  A lane takes RB CONSECUTIVE minimizers (RB = 1 .. 4 by the tile's count: 64 RB of them per
+    //      batch, one batch as a rule), so that only its first window pays the closed form (src/lib.rs:275-288: 2 k rotations of 64 bits) and the next
+    //      ones ROLL (src/lib.rs:243-249: F' = rotl(F, 1) ^ rotl(out, k) ^ in, Rv' = rotr(Rv ^ out, 1) ^ rotl(in, k-1): 14 instructions instead of 58).
+    //      The k-1 minimizers before a lane's first are the last ones of the lanes before it: they come over DPP (wave_shr:1, chained; lane 0 is
+    //      handed the minimizers before the batch through the instruction's "old" operand), not through LDS -- no ring of a round's mixed hashes, no
+    //      barriers in the loop, 5.5 -> 3.5 KiB of LDS per block.  (Rounds 3-5: one minimizer per lane and round, every window by the closed form over
+    //      ten ring reads: 130 vector + 15 LDS instructions per round of 64, three rounds per Hpc tile.)
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u4v lds_u4;
+    typedef __attribute__((address_space(3))) uint32_t lds_u1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[]; // COAL: DK_WAVES staging areas
+    const uint32_t stage = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_dyn + (uint32_t)DK_STAGE_BYTES * (uint32_t)w;
+    (void)stage;
+    static_assert(!COAL || FULL, "the staged stores write all four arrays");
+    auto batch = [&](auto rb_c, uint32_t b0) {
+        constexpr int RB = decltype(rb_c)::value;
+        static_assert(64 * RB <= DK_STAGE_RECS, "a batch fits the staging area");
+        int lane_b = lane; // (opaque per batch: what is derived from the lane index -- LDS addresses, offsets -- is otherwise hoisted out of the batch loop and spilled)
+        asm volatile("" : "+v"(lane_b));
+        constexpr int S = ((int)KT - 1 + RB - 1) / RB; // lanes back that hold the k-1 minimizers before a lane_b's first
+        constexpr int K1c = KT - 1;
+        const uint32_t i0 = b0 + (uint32_t)RB * (uint32_t)lane_b; // this lane_b's first minimizer
+        uint32_t h32[RB], pos[RB];
+        // the lane_b's records: RB consecutive entries of each array (reads past the tile's last record stay inside the pool: the arena keeps slack)
+        if (i0 < N) {
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                h32[r] = rec.hash[base + i0 + r];
+                pos[r] = rec.j[base + i0 + r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RB; r++) h32[r] = pos[r] = 0u;
+        }
+        // Z[u], u = -(k-1) .. RB-1: mixed hash (src/lib.rs:157-169) of the minimizer u places from the lane_b's first.  u >= 0: the lane_b's own; u < 0: they
+        // come down the lanes level by level (level s = the values of the lane_b s places back, slot r -> u = r - RB s), and every level is folded into the
+        // first window's closed form  F = XOR rotl(Z[u], -u),  Rv = XOR rotl(Z[u], u + k - 1)  (src/lib.rs:275-288) as it arrives: one level is live at a time
+        uint32_t xl[RB], xh[RB], jj[RB];     // the lane_b's own
+        uint32_t cl[RB], ch[RB], cj[RB];     // the level in flight
+        uint32_t outl[RB], outh[RB], js[RB]; // what the rolls and the records need later: Z[r - 1 - (k-1)] (r >= 1), j of Z[r - (k-1)]
+        uint32_t jend[RB];
+        uint32_t before[RB], adj[RB]; // rank of the hit inside its read; hit index -> index among the tile's windows
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            const uint64_t xm = mix32(h32[r]);
+            xl[r] = cl[r] = (uint32_t)xm;
+            xh[r] = ch[r] = (uint32_t)(xm >> 32);
+            const uint32_t i = i0 + (uint32_t)r;
+            uint32_t c = (uint32_t)(sb1 <= i) + (uint32_t)(sb2 <= i);
+#pragma nounroll
+            for (uint32_t sq = 3; sq <= nb; sq++) c += (s_seg[w][sq].x <= i); // (more than two read starts in a tile: rare; wave-uniform trip count)
+            const uint4 sg = s_seg[w][c];
+            before[r] = (c == 0 ? p_in : 0u) + (i - sg.x);
+            adj[r] = sg.y;
+            jj[r] = cj[r] = sg.z + (pos[r] & 0x3FFFu);
+            jend[r] = jj[r] + (pos[r] >> 14);
+            outl[r] = outh[r] = js[r] = 0u;
+        }
+        auto rot_lo = [](uint32_t lo, uint32_t hi, int c) { return c ? __builtin_amdgcn_alignbit(lo, hi, 32 - c) : lo; }; // low word of rotl64(x, c), 0 <= c < 32
+        auto rot_hi = [](uint32_t lo, uint32_t hi, int c) { return c ? __builtin_amdgcn_alignbit(hi, lo, 32 - c) : hi; };
+        // F / Rv of the lane_b's first window, terms folded two at a time with the three-input xor (v_bitop3_b32)
+        uint32_t fl = xl[0], fh = xh[0], rl = rot_lo(xl[0], xh[0], K1c), rh = rot_hi(xl[0], xh[0], K1c); // u = 0
+        uint32_t pfl = 0, pfh = 0, prl = 0, prh = 0; // a term waiting for its partner
+        bool have = false;                            // (compile-time once unrolled)
+#pragma unroll
+        for (int sl = 1; sl <= S; sl++) {
+#pragma unroll
+            for (int r = RB - 1; r >= 0; r--) {
+                const int m = RB * sl - r; // the level's slot r: Z[-m]; lane_b 0's value: the m-th minimizer before the batch
+                unsigned long long cx = 0;
+                uint32_t cjv = 0;
+                if (m <= K1c) { // (every lane_b reads the same address: a broadcast)
+                    cx = s_ring[w][K1c - m];
+                    cjv = s_jcar[w][K1c - m];
+                }
+                // (a slot is carried down only as far as somebody needs it: Z[-m] for m <= k-1, its j for the records' start positions)
+                bool deeper = false;
+                for (int s2 = sl; s2 <= S; s2++) deeper = deeper || RB * s2 - r <= K1c;
+                if (!deeper) continue;
+                cl[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)cx, (int)cl[r], 0x138, 0xf, 0xf, false); // wave_shr:1 -- lane_b 0 keeps "old"
+                ch[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(cx >> 32), (int)ch[r], 0x138, 0xf, 0xf, false);
+                bool j_deeper = false;
+                for (int s2 = sl; s2 <= S; s2++) j_deeper = j_deeper || (RB * s2 - r <= K1c && RB * s2 - r > K1c - RB);
+                if (j_deeper) cj[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)cjv, (int)cj[r], 0x138, 0xf, 0xf, false);
+                if (m > K1c) continue;
+                const uint32_t tfl = rot_lo(cl[r], ch[r], m), tfh = rot_hi(cl[r], ch[r], m), trl = rot_lo(cl[r], ch[r], K1c - m), trh = rot_hi(cl[r], ch[r], K1c - m);
+                if (have) {
+                    fl = xor3(fl, pfl, tfl);
+                    fh = xor3(fh, pfh, tfh);
+                    rl = xor3(rl, prl, trl);
+                    rh = xor3(rh, prh, trh);
+                    have = false;
+                } else {
+                    pfl = tfl, pfh = tfh, prl = trl, prh = trh;
+                    have = true;
+                }
+                const int rr = K1c - m; // record rr of the lane_b starts its window at Z[-m]; record rr + 1 drops it when it rolls
+                if (rr >= 0 && rr < RB) js[rr] = cj[r];
+                if (rr + 1 >= 1 && rr + 1 < RB) outl[rr + 1] = cl[r], outh[rr + 1] = ch[r];
+            }
+        }
+        if (have) {
+            fl ^= pfl;
+            fh ^= pfh;
+            rl ^= prl;
+            rh ^= prh;
+        }
+        // (records whose window starts at one of the lane_b's own: k - 1 < RB never happens for k >= 5, RB <= 4)
+        static_assert(KT - 1 >= 4, "a window starts before the lane_b's own minimizers");
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            if (r > 0) { // roll: the window loses Z[r-1-(k-1)] and takes Z[r]
+                const uint32_t ol = outl[r], oh = outh[r], il = xl[r], ih = xh[r];
+                static_assert(KT < 32, "rotations below are by less than a word");
+                const uint32_t nfl = xor3(__builtin_amdgcn_alignbit(fl, fh, 31), rot_lo(ol, oh, KT), il); // rotl(F, 1) ^ rotl(out, k) ^ in
+                const uint32_t nfh = xor3(__builtin_amdgcn_alignbit(fh, fl, 31), rot_hi(ol, oh, KT), ih);
+                const uint32_t tl = rl ^ ol, th = rh ^ oh;                                                  // rotr(Rv ^ out, 1) ^ rotl(in, k-1)
+                const uint32_t nrl = __builtin_amdgcn_alignbit(th, tl, 1) ^ rot_lo(il, ih, K1c);
+                const uint32_t nrh = __builtin_amdgcn_alignbit(tl, th, 1) ^ rot_hi(il, ih, K1c);
+                fl = nfl, fh = nfh, rl = nrl, rh = nrh;
+            }
+            const uint32_t i = i0 + (uint32_t)r;
+            const bool act = i < N;
+            // rank of the hit inside its read, capped: the window that ENDS here exists iff k-1 minimizers of the read precede it (src/lib.rs:235)
+            const bool win = act && before[r] >= K1;
+            const uint64_t f = ((uint64_t)fh << 32) | fl, rvv = ((uint64_t)rh << 32) | rl;
+            const uint64_t hmin = f < rvv ? f : rvv;
+            const uint32_t jstart = js[r]; // start = j of the window's first minimizer, k-1 hits back
+            if constexpr (COAL) {
+                const uint32_t e = (uint32_t)RB * (uint32_t)lane_b + (uint32_t)r; // the minimizer's place in the batch
+                if (win) xacc ^= hmin;
+                *reinterpret_cast<lds_u4 *>(stage + 16u * e) = u4v{(uint32_t)hmin, (uint32_t)(hmin >> 32), jstart, jend[r]};
+                *reinterpret_cast<lds_u1 *>(stage + 16u * DK_STAGE_RECS + 4u * e) = win ? ((i + adj[r]) | (rvv < f ? 0x80000000u : 0u)) : 0xFFFFFFFFu;
+            } else
+            if (win) {
+#ifdef S2K_KM_FAKE_COAL // (timing experiment only, WRONG results: what would the kernel take if its stores were contiguous across the lanes?)
+                const uint32_t ot = b0 + 64u * (uint32_t)r + (uint32_t)lane_b + (adj[r] & 0u);
+#else
+                const uint32_t ot = i + adj[r]; // index among the tile's windows (>= 0 for a window)
+#endif
+                xacc ^= hmin;
+                if (tile_fits) { // (wave-uniform) FULL and everything fits: scalar base + 32-bit offset, no tests
+                    t_hash[ot] = hmin;
+                    t_start[ot] = jstart;
+                    t_end[ot] = jend[r];
+                    t_rev[ot] = (uint8_t)(rvv < f); // src/lib.rs:250-251
+                } else {
+                    const uint64_t o = G + (uint64_t)ot;
+                    if (o < dz.km_capacity) {
+                        if (dz.o_hash) dz.o_hash[o] = hmin;
+                        if (dz.o_start) dz.o_start[o] = jstart;
+                        if (dz.o_end) dz.o_end[o] = jend[r];
+                        if (dz.o_rev) dz.o_rev[o] = (uint8_t)(rvv < f);
+                    }
+                }
+            }
+            if (!FULL && dz.mn_capacity && act) { // optional minimizer triples (NtHashHPCIterator::Item, src/nthash_hpc.rs:193)
+                const uint64_t g = Gmn + i;
+                if (g < dz.mn_capacity) {
+                    dz.o_mn_j[g] = jj[r];
+                    dz.o_mn_jend[g] = jend[r];
+                    dz.o_mn_hash[g] = h32[r];
+                }
+            }
+        }
+        if constexpr (COAL) { // every store instruction: 64 consecutive minimizers of the batch -> (all but) consecutive windows
+            wave_sync();
+#pragma unroll
+            for (int jr = 0; jr < RB; jr++) {
+                const uint32_t e = 64u * (uint32_t)jr + (uint32_t)lane_b;
+                const u4v v = *reinterpret_cast<lds_u4 *>(stage + 16u * e);
+                const uint32_t oo = *reinterpret_cast<lds_u1 *>(stage + 16u * DK_STAGE_RECS + 4u * e);
+                if (oo != 0xFFFFFFFFu) {
+                    const uint32_t ot = oo & 0x7FFFFFFFu;
+                    const unsigned long long hm = ((unsigned long long)v.y << 32) | v.x;
+                    if (tile_fits) {
+                        t_hash[ot] = hm;
+                        t_start[ot] = v.z;
+                        t_end[ot] = v.w;
+                        t_rev[ot] = (uint8_t)(oo >> 31); // src/lib.rs:250-251
+                    } else if (G + (uint64_t)ot < dz.km_capacity) {
+                        dz.o_hash[G + ot] = hm;
+                        dz.o_start[G + ot] = v.z;
+                        dz.o_end[G + ot] = v.w;
+                        dz.o_rev[G + ot] = (uint8_t)(oo >> 31);
+                    }
+                }
+            }
+            wave_sync();
+        }
+        if (b0 + 64u * (uint32_t)RB < N) { // (rare) another batch follows: its "minimizers before" are the last k-1 of this one
+            wave_sync();
+            const int back = 63 - lane_b; // lanes 63, 62, ...: the m-th before the next batch, m = RB back + RB - r
+            if (back < S) {
+#pragma unroll
+                for (int r = 0; r < RB; r++) {
+                    const int m = RB * back + RB - r;
+                    if (m <= K1c) {
+                        s_ring[w][K1c - m] = ((unsigned long long)xh[r] << 32) | xl[r];
+                        s_jcar[w][K1c - m] = jj[r];
+                    }
+                }
+            }
+            wave_sync();
+        }
+    };
+    for (uint32_t b0 = 0; b0 < N;) { // one batch as a rule: 137 +- 11 minimizers per Hpc tile of uniform ACGT, 184 +- 13 per Regular tile (then 192 + the rest)
+        const uint32_t rem = N - b0;
+        if (rem <= 64u) batch(std::integral_constant<int, 1>{}, b0), b0 += 64u;
+        else if (rem <= 128u) batch(std::integral_constant<int, 2>{}, b0), b0 += 128u;
+        else batch(std::integral_constant<int, 3>{}, b0), b0 += 192u;
+    }
+    } else {
+    uint32_t jprev = p_in && (uint32_t)lane >= 64u - K1 ? s_jcar[w][lane - (64u - K1)] : 0u; // "the round before the first": the k-1 minimizers before the tile
     for (uint32_t i0 = 0; i0 < N; i0 += 64) {
         const uint32_t i = i0 + lane;
         const bool act = i < N;
@@ -327,16 +545,16 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
         }
         uint32_t c = (uint32_t)(sb1 <= i) + (uint32_t)(sb2 <= i);
 #pragma nounroll // (more than two read starts in a tile: the walk; unrolled 31 times, the loop was most of the kernel's code)
-        for (uint32_t s = 3; s <= nb; s++) c += (s_segb[w][s] <= i); // wave-uniform trip count, LDS broadcast
-        const uint64_t rstart = s_rs[w][c];
-        const uint32_t j = (uint32_t)(t0 + (pos & 0x3FFFu) - rstart);
+        for (uint32_t s = 3; s <= nb; s++) c += (s_seg[w][s].x <= i); // wave-uniform trip count, LDS broadcast
+        const uint4 sg = s_seg[w][c];
+        const uint32_t j = sg.z + (pos & 0x3FFFu);
         const uint32_t jend = j + (pos >> 14);
         const uint64_t xm = mix32(h32); // src/lib.rs:157-169
         wave_sync();
         s_ring[w][K1 + lane] = xm;
         wave_sync();
         // rank of the hit inside its read, capped: the window that ENDS here exists iff k-1 minimizers of the read precede it
-        const uint32_t before = (c == 0 ? p_in : 0u) + (i - s_segb[w][c]);
+        const uint32_t before = (c == 0 ? p_in : 0u) + (i - sg.x);
         const bool win = act && before >= K1;
         // F = XOR rotl(x_m, k-1-m), Rv = XOR rotl(x_m, m) over the window (src/lib.rs:238-249, closed form :275-288); ring[lane + m] = hit i - (k-1) + m
         uint32_t fl = 0, fh = 0, rl = 0, rh = 0;
@@ -397,7 +615,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
         const uint32_t jstart = (uint32_t)lane >= K1 ? jsame : jbefore;
         const uint64_t hmin = f < rvv ? f : rvv;
         if (win) {
-            const uint32_t ot = (uint32_t)((int32_t)i + s_adj[w][c]); // index among the tile's windows (>= 0 for a window)
+            const uint32_t ot = i + sg.y; // index among the tile's windows (>= 0 for a window)
             xacc ^= hmin;
             if (tile_fits) { // (wave-uniform) FULL and everything fits: scalar base + 32-bit offset, no tests
                 t_hash[ot] = hmin;
@@ -425,6 +643,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
         wave_sync();
         if ((uint32_t)lane >= 64u - K1) s_ring[w][lane - (64u - K1)] = xm; // the last k-1 hits of a full round lead the next one
         jprev = j;
+    }
     }
     for (int o = 32; o > 0; o >>= 1) xacc ^= __shfl_xor(xacc, o);
     if (lane == 0 && xacc) atomicXor((unsigned long long *)&dz.xor_shards[t & (XOR_SHARDS - 1)], (unsigned long long)xacc);
@@ -456,7 +675,7 @@ hipError_t launch_desc_scan(uint64_t tile_begin, uint64_t tile_end, Desc dz, uns
 }
 
 hipError_t launch_desc_kminmers(uint64_t tile_begin, uint64_t tile_end, uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts,
-                                hipStream_t st) {
+                                hipStream_t st, bool alone) {
     if (tile_end <= tile_begin) return hipSuccess;
     if (dz.k == 0 || dz.k > (uint32_t)DK_KMAX || rec.slab_cap < 64) return hipErrorInvalidValue;
     const dim3 g((unsigned)((tile_end - tile_begin + DK_WAVES - 1) / DK_WAVES)), b(64 * DK_WAVES);
@@ -465,11 +684,15 @@ hipError_t launch_desc_kminmers(uint64_t tile_begin, uint64_t tile_end, uint64_t
     if (const char *e = getenv("S2K_DEBUG_KM_LDS")) pad = (unsigned)atoi(e);
 #endif
     const bool full = dz.o_hash && dz.o_start && dz.o_end && dz.o_rev && dz.mn_capacity == 0;
-#define S2K_KM_GO(KT, F) hipLaunchKernelGGL((desc_kminmer_kernel<KT, F>), g, b, pad, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts)
+    // alone: nothing runs beside this kernel (the caller launched it behind the minimizer kernel): staged, line-filling stores (COAL)
+    static const bool no_coal = getenv("S2K_KM_NO_COAL") != nullptr; // (A/B runs)
+    const bool coal = alone && full && !no_coal && (dz.k == 10 || dz.k == 5);
+#define S2K_KM_GO(KT, F, C) \
+    hipLaunchKernelGGL((desc_kminmer_kernel<KT, F, C>), g, b, (C) ? (unsigned)(DK_WAVES * DK_STAGE_BYTES) : pad, st, tile_begin, tile_end, n_tiles, n_reads, dz, rec, counts)
     switch (dz.k) { // the benchmark's k and the reference demo's (src/main.rs:13-48) get an unrolled window loop
-    case 10: if (full) S2K_KM_GO(10, true); else S2K_KM_GO(10, false); break;
-    case 5: if (full) S2K_KM_GO(5, true); else S2K_KM_GO(5, false); break;
-    default: if (full) S2K_KM_GO(0, true); else S2K_KM_GO(0, false); break;
+    case 10: if (coal) S2K_KM_GO(10, true, true); else if (full) S2K_KM_GO(10, true, false); else S2K_KM_GO(10, false, false); break;
+    case 5: if (coal) S2K_KM_GO(5, true, true); else if (full) S2K_KM_GO(5, true, false); else S2K_KM_GO(5, false, false); break;
+    default: if (full) S2K_KM_GO(0, true, false); else S2K_KM_GO(0, false, false); break;
     }
 #undef S2K_KM_GO
     return hipGetLastError();

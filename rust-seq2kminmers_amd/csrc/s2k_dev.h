@@ -287,8 +287,9 @@ hipError_t launch_tile_minimizers(const uint8_t *bases, const uint64_t *read_off
 hipError_t launch_desc_scan(uint64_t tile_begin, uint64_t tile_end, Desc dz, unsigned long long *scan_tmp /* desc_scan_tmp_words(n_tiles) */,
                             const Counts *counts, hipStream_t st);
 size_t desc_scan_tmp_words(uint64_t n_tiles);
+// alone: no other kernel of the call runs beside this launch (it may use the CU's LDS for staged, line-filling stores)
 hipError_t launch_desc_kminmers(uint64_t tile_begin, uint64_t tile_end, uint64_t n_tiles, uint64_t n_reads, Desc dz, Records rec, Counts *counts,
-                                hipStream_t st);
+                                hipStream_t st, bool alone);
 
 hipError_t launch_hpc_count(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint32_t *run_cnt, hipStream_t st,
                             bool rle = false);

@@ -169,7 +169,16 @@ constexpr int SEL8_OFF = SEED_TABLE_BYTES, SEL8_BYTES = S2K_SEL8 ? 256 * 8 : 0;
 #define S2K_PASS2_ACC 1 // Hpc compaction, pass 2: 1 = eight raw bytes per step, packed by v_perm_b32 and placed with aligned LDS operations (round 5), 0 = one byte store per raw byte (rounds 1-4)
 #endif
 static_assert(!S2K_PASS2_ACC || S2K_SEL8, "pass 2 reads its v_perm_b32 selectors from sel8");
-template <bool HPC> constexpr int table_bytes() { return SEED_TABLE_BYTES + (HPC ? SEL8_BYTES : 0); }
+#ifndef S2K_LPH
+#define S2K_LPH 0 // 1 = Hpc hits listed one lane per hit (round 6 experiment, dense_phase: 2.4 % SLOWER, profiles/r06_steady_tile1.txt); 0 = every lane lists its own in a loop
+#endif
+#ifndef S2K_WARM2
+#define S2K_WARM2 1 // Hpc: a third seed table with the rotations of a warm-up PAIR's first base pre-applied (round 6; the Regular block has no LDS left for it)
+#endif
+// Hpc: behind sel8, WARM[c] = {rotl(h[c], 1), rotr(IN[c].y, 1)}: the first l-mer of a lane is then built two bases per step as
+// fh = rotl(fh, 2) ^ WARM[s[i]] ^ IN[s[i+1]] -- one rotation and one three-input xor per strand and pair instead of two rotations and the xor
+constexpr int WARM_OFF = SEL8_OFF + SEL8_BYTES, WARM_BYTES = S2K_WARM2 ? 256 * 8 : 0;
+template <bool HPC> constexpr int table_bytes() { return SEED_TABLE_BYTES + (HPC ? SEL8_BYTES + WARM_BYTES : 0); }
 template <bool HPC>
 constexpr int block_lds_bytes() { return table_bytes<HPC>() + tw<HPC>() * (int)sizeof(WaveLdsT<HPC>) + PROFILE_LDS_BYTES; }
 // one block of tw<HPC>() waves per CU: it may use the whole 160 KiB (MI355X_MICROARCH.md: "a single workgroup may declare all 160 KiB")
@@ -195,6 +204,25 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
     a += t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
     a += t;
+    return a;
+}
+// inclusive MAX scan over the 64 lanes (values >= 0), same DPP steps
+__device__ inline uint32_t wave_incl_max(uint32_t v) {
+    uint32_t t, a;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    a = v > t ? v : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    a = a > t ? a : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false); // row_shr:3
+    a = a > t ? a : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x114, 0xf, 0xe, false); // row_shr:4, banks 1-3
+    a = a > t ? a : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x118, 0xf, 0xc, false); // row_shr:8, banks 2-3
+    a = a > t ? a : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+    a = a > t ? a : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
+    a = a > t ? a : t;
     return a;
 }
 // value of lane `src` (wave-uniform index) in every lane: v_readlane, no LDS round trip
@@ -327,7 +355,7 @@ __device__ __forceinline__ void close_piece(uint32_t &bits, uint32_t (&raw)[5]) 
 // l-mer at position p = s - L is complete, so it is tested and then rolled forward with OUT[p], IN[s].
 // W[] holds the lane's stream as dwords (piece j = W[4j .. 4j+3], read one piece ahead of its first use); only the
 // ~12 dwords between the outgoing and the incoming base are live at any time.
-template <int L, int T, int LA, int S>
+template <int L, int T, int LA, bool W2, int S>
 __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * ((T + L + 15) / 16)], uint32_t (&A)[T + L],
                                            uint2 (&EI)[T + L], uint2 (&EO)[T], uint32_t &fh, uint32_t &rh, uint32_t (&caps)[NPC], uint32_t (&raw)[5],
                                            uint32_t &bits, uint32_t bound, int np) {
@@ -356,7 +384,10 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * (
 #define S2K_IN(J)                                                        \
     if constexpr (J < LA && G + J < T + L - 1) {                          \
         A[G + J] = byte_x8<(G + J) & 3>(W[(G + J) >> 2]);                  \
-        EI[G + J] = seed_pair<0>(A[G + J]);                                \
+        if constexpr (W2 && (G + J) % 2 == 0 && G + J + 1 < L)             \
+            EI[G + J] = seed_pair<WARM_OFF>(A[G + J]); /* first base of a warm-up pair */ \
+        else                                                               \
+            EI[G + J] = seed_pair<0>(A[G + J]);                            \
     }
             S2K_IN(0) S2K_IN(1) S2K_IN(2) S2K_IN(3) S2K_IN(4) S2K_IN(5) S2K_IN(6) S2K_IN(7)
 #undef S2K_IN
@@ -369,7 +400,15 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * (
         if constexpr (S < L) { // warm-up: first l-mer of the lane (src/nthash_hpc.rs:138-150,158-174), in closed form: base i enters
             // as rotl(h, l-1-i) / rotl(rc-entry, i) -- EI.y holds rotl(rc, l-1), so rotr by l-1-i --, two bases per three-input XOR
             // (three instructions per strand and pair instead of four for two rolling steps)
-            if constexpr (S % 2 == 1) {
+            if constexpr (W2) { // Horner, two bases per step: the pair's first base comes from the pre-rotated table (see S2K_IN)
+                if constexpr (S % 2 == 1) {
+                    fh = xor3(S == 1 ? 0u : __builtin_rotateleft32(fh, 2), EI[S - 1].x, EI[S].x);
+                    rh = xor3(S == 1 ? 0u : __builtin_rotateright32(rh, 2), EI[S - 1].y, EI[S].y);
+                } else if constexpr (S == L - 1) { // odd l: the last base alone
+                    fh = __builtin_rotateleft32(fh, 1) ^ EI[S].x;
+                    rh = __builtin_rotateright32(rh, 1) ^ EI[S].y;
+                }
+            } else if constexpr (S % 2 == 1) {
                 fh = xor3(fh, __builtin_rotateleft32(EI[S - 1].x, (L - S) & 31), __builtin_rotateleft32(EI[S].x, (L - 1 - S) & 31));
                 rh = xor3(rh, __builtin_rotateright32(EI[S - 1].y, (L - S) & 31), __builtin_rotateright32(EI[S].y, (L - 1 - S) & 31));
             } else if constexpr (S == L - 1) { // odd l: the last base alone, rotation 0
@@ -387,7 +426,7 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * (
                 if (P / 16 + 1 >= np) return; // wave-uniform: the (compacted) tile is shorter than 144 bases per lane
             }
         }
-        hash_steps<L, T, LA, S + 1>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
+        hash_steps<L, T, LA, W2, S + 1>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
     } else { // last position: test only, nothing left to roll into
         const uint32_t hv = fh < rh ? fh : rh;
         hit_track(hv, bound, caps[(T - 1) / CAPP], bits);
@@ -395,7 +434,7 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * (
     }
 }
 
-template <int L, int LA>
+template <int L, int LA, bool W2>
 __device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t bound, int lane, int np, uint32_t (&caps)[NPC],
                                                  uint32_t (&raw)[5]) {
     constexpr int T = TILE_T;
@@ -418,9 +457,9 @@ __device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t boun
     A[0] = byte_x8<0>(W[0]); A[1] = byte_x8<1>(W[0]); A[2] = byte_x8<2>(W[0]); A[3] = byte_x8<3>(W[0]);
     if constexpr (LA > 4) { A[4] = byte_x8<0>(W[1]); A[5] = byte_x8<1>(W[1]); A[6] = byte_x8<2>(W[1]); A[7] = byte_x8<3>(W[1]); }
 #pragma unroll
-    for (int i = 0; i < LA; i++) EI[i] = seed_pair<0>(A[i]);
+    for (int i = 0; i < LA; i++) EI[i] = (W2 && i % 2 == 0 && i + 1 < L) ? seed_pair<WARM_OFF>(A[i]) : seed_pair<0>(A[i]);
     uint32_t fh = 0, rh = 0, bits = 0;
-    hash_steps<L, T, LA, 0>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
+    hash_steps<L, T, LA, W2, 0>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
 }
 
 // Same loop for a run-time l (1 .. 64; only l values without a static instantiation come here), unrolled like the static one.  The
@@ -513,7 +552,7 @@ __device__ __forceinline__ void hash_stage(const uint8_t *D, const uint2 *tab, u
     for (int g = 0; g < NPC; g++) caps[g] = 0;
 #pragma unroll
     for (int w = 0; w < 5; w++) raw[w] = 0;
-    if constexpr (L > 0) hash_loop_static<L, HPC ? HPC_LA : REG_LA>(D, bound, lane, np, caps, raw);
+    if constexpr (L > 0) hash_loop_static<L, HPC ? HPC_LA : REG_LA, HPC && S2K_WARM2 != 0>(D, bound, lane, np, caps, raw);
     else hash_loop_dynamic(D, tab, bound, lane, l, np, caps, raw);
 }
 
@@ -1325,8 +1364,88 @@ __device__ __forceinline__ uint32_t dense_phase(IssueNext &&issue_next, WL &S, c
     auto batch = [&](uint32_t b0, auto single_c) {
         constexpr bool SINGLE = decltype(single_c)::value;
         wave_sync();
+        // Hpc tiles of at most 112 hash positions per lane (all but incompressible input) whose hits fit one batch: ONE LANE PER HIT (round 6).  The
+        // loop below runs one trip per hit of the busiest lane AND word (~14 trips of ~27 instructions for 137 hits); here the lanes leave their hit
+        // masks in the part of the tile buffer the compacted tile does not reach (Tq <= 112 -> nh <= 7168: 2 KiB free behind the run heads that
+        // follow the tile), and hit k finds its owner (a directory of first hits + a max scan), its word (cumulative counts, as the back-map does),
+        // its bit (sel8) and whether a later raw hit of the same 16-position piece took the kept hash; then the kept hashes take the masks' place
+        // and every hit that owns one fetches and stores it -- coalesced.
+        bool listed = false;
+        if constexpr (HPC && SINGLE && S2K_LPH != 0) {
+            if (Tq <= 112u) {
+                listed = true;
+                typedef __attribute__((address_space(3))) uint8_t lds_b;
+                typedef __attribute__((address_space(3))) uint32_t lds_w;
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2))); // (plain vector types: HIP's uint2 / uint4 classes cannot be assigned through an LDS pointer)
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(3))) u32x2 lds_w2;
+                typedef __attribute__((address_space(3))) u32x4 lds_w4;
+                constexpr uint32_t XT = TILE_BASES + 128 - 2048; // 7296: behind nh + the run heads that follow the tile (<= 7168 + 80)
+                static_assert(XT % 16 == 0 && XT >= 7168 + MAX_L_TILED + 16 && LISTCAP <= 192, "the tables of the listing must not reach into the compacted tile");
+                const uint32_t dq = (uint32_t)(uintptr_t)(lds_b *)const_cast<uint8_t *>(D) + XT; // masks: 64 x 16 B; behind them {offset | cum, last hit of every piece}: 64 x 8 B; directory: 192 B
+                constexpr uint32_t T2O = 1024, DIRO = 1536;
+                if (lane < 12) *reinterpret_cast<lds_w4 *>(dq + DIRO + 16u * (uint32_t)lane) = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<lds_w4 *>(dq + 16u * (uint32_t)lane) = u32x4{vm[0], vm[1], vm[2], vm[3]};
+                const uint32_t c0 = __popc(vm[0]), c1 = c0 + __popc(vm[1]), c2 = c1 + __popc(vm[2]);
+                // position (0 .. 15) of the LAST raw hit of each of the lane's seven pieces, a nibble each: the kept hash of a piece is that hit's
+                uint32_t lp = 0;
+#pragma unroll
+                for (int pc = 0; pc < 7; pc++) {
+                    const uint32_t hw = (pc & 1) ? raw[pc >> 1] >> 16 : raw[pc >> 1] & 0xFFFFu;
+                    lp |= (31u - (uint32_t)__builtin_clz(hw | 1u)) << (4 * pc); // (hw < 2^16: 0 .. 15; a piece without a raw hit has no hit to ask)
+                }
+                *reinterpret_cast<lds_w2 *>(dq + T2O + 8u * (uint32_t)lane) = u32x2{c0 | (c1 << 8) | (c2 << 16) | (myoff << 24), lp}; // (myoff <= N <= 192)
+                if (cnt) *reinterpret_cast<lds_b *>(dq + DIRO + myoff) = (uint8_t)(lane + 1); // (DS operations of a wave execute in order: the zeros above are in place)
+                wave_sync();
+                uint32_t own[3] = {0, 0, 0}; // per round of 64 hits: owner lane | piece << 8 | "kept hash is not mine" << 15
+                uint32_t carry = 0;
+#pragma unroll
+                for (int rd = 0; rd < 3; rd++) {
+                    if (64u * rd < N) { // (wave-uniform)
+                        const uint32_t kq = 64u * rd + (uint32_t)lane;
+                        const bool act = kq < N;
+                        uint32_t dv = act ? (uint32_t)*reinterpret_cast<lds_b *>(dq + DIRO + kq) : 0u;
+                        dv = wave_incl_max(dv);
+                        dv = dv > carry ? dv : carry;
+                        carry = bcast(dv, 63);
+                        const uint32_t o = act ? dv - 1u : 0u; // (hit 0 belongs to the first lane that has one: dv >= 1 for every hit)
+                        const u32x2 t2 = *reinterpret_cast<lds_w2 *>(dq + T2O + 8u * o);
+                        const uint32_t n = kq - (t2.x >> 24); // rank of the hit among its lane's
+                        uint32_t g = 0;               // the word that holds it: number of cumulative counts <= n
+                        asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                            "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+                            "v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:BYTE_1\n\t"
+                            "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+                            "v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:BYTE_2\n\t"
+                            "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc"
+                            : "+v"(g)
+                            : "v"(n), "v"(t2.x)
+                            : "vcc");
+                        if (!act) g = 0;
+                        const uint32_t hbw = heads_before_word(t2.x, g); // hits of the lane before word g
+                        const uint32_t wv = *reinterpret_cast<lds_w *>(dq + 16u * o + 4u * g);
+                        const uint32_t ps = 32u * g + select_nth_32_lut(wv, act ? n - hbw : 0u); // position inside the lane
+                        const uint32_t piece = ps >> 4;
+                        const bool later = ((t2.y >> (4u * piece)) & 15u) != (ps & 15u);
+                        if (act) S.list[kq] = (uint16_t)((__umul24(Tq, o) + ps) | (later ? 0x8000u : 0u));
+                        own[rd] = o | (piece << 8) | (later || !act ? 0x8000u : 0u);
+                    }
+                }
+                wave_sync(); // the masks are dead: the kept hashes take their place, piece-major (lane stride 4 B: conflict-free)
+#pragma unroll
+                for (int pc = 0; pc < 7; pc++) *reinterpret_cast<lds_w *>(dq + 256u * pc + 4u * (uint32_t)lane) = caps[pc];
+                wave_sync();
+#pragma unroll
+                for (int rd = 0; rd < 3; rd++) {
+                    if (64u * rd < N && !(sem.dbg_skip & 16)) {
+                        if (!(own[rd] & 0x8000u))
+                            rec.hash[base + 64u * rd + (uint32_t)lane] = *reinterpret_cast<lds_w *>(dq + 256u * ((own[rd] >> 8) & 15u) + 4u * (own[rd] & 0xFFu));
+                    }
+                }
+            }
+        }
         // every lane lists its own hits and stores the kept hash of those that were the last raw hit of their piece
-        {
+        if (!listed) {
             uint32_t k = myoff;
 #pragma unroll
             for (int d = 0; d < 5; d++) {
@@ -1505,6 +1624,12 @@ __global__ __launch_bounds__(64 * tw<HPC>(), waves_per_simd<HPC>()) void tile_mi
         tab[c] = make_uint2(h, rotl32(r, l - 1));
         tab[256 + c] = make_uint2(rotl32(h, l), rotr32(r, 1));
     }
+    if constexpr (HPC && S2K_WARM2 != 0)
+        for (int c = threadIdx.x; c < 256; c += 64 * TW) {
+            const uint32_t cc = c;
+            const uint32_t h = sem.simd_seeds ? seed_h_simd(cc) : seed_h_scalar(cc), r = sem.simd_seeds ? seed_rc_simd(cc) : seed_rc_scalar(cc);
+            reinterpret_cast<uint2 *>(smem + WARM_OFF)[c] = make_uint2(rotl32(h, 1), rotr32(rotl32(r, l - 1), 1));
+        }
     if constexpr (HPC && S2K_SEL8 != 0)
         for (int c = threadIdx.x; c < 256 * 8; c += 64 * TW) {
             const uint32_t m = (uint32_t)c >> 3, n = (uint32_t)c & 7u;
@@ -1612,6 +1737,9 @@ __global__ __launch_bounds__(64 * tw<HPC>(), waves_per_simd<HPC>()) void tile_mi
         r1n = tile_read0[tn + 1];
     }
 
+#ifdef S2K_TILE_PRIO // (experiment: the persistent kernel's waves above the k-min-mer kernel's beside them in the SIMD's issue arbitration)
+    if (!sem.tile_heads) __builtin_amdgcn_s_setprio(S2K_TILE_PRIO);
+#endif
     uint32_t prio_iter = 0;
     // HpcSimd look-back (lookback_heads): a wave that has waited in vain once does not wait again -- nor does any wave once the
     // call is known to be run again (need_runs; e.g. the minimizer kernel of a later chunk)

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * TW, S2K_WAVES_PER_SIMD) void hl_kernel(uint32_
         for (int g = 0; g < NPC; g++) caps[g] = 0;
 #pragma unroll
         for (int g = 0; g < 5; g++) raw[g] = 0;
-        hash_loop_static<L, LA>(D, bound, lane, np, caps, raw);
+        hash_loop_static<L, LA, false>(D, bound, lane, np, caps, raw);
         wave_sync();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

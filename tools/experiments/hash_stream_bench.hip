@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * TW, (TW * HS_BPC + 3) / 4) void hs_kernel(cons
         for (int g = 0; g < NPC; g++) caps[g] = 0;
 #pragma unroll
         for (int g = 0; g < 5; g++) raw[g] = 0;
-        hash_loop_static<L, LA>(bases + t * (uint64_t)TILE_BASES, bound, lane, 9, caps, raw);
+        hash_loop_static<L, LA, false>(bases + t * (uint64_t)TILE_BASES, bound, lane, 9, caps, raw);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < NPC; g++) acc ^= caps[g];
