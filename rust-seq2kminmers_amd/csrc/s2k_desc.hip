@@ -219,9 +219,18 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
     const uint32_t r0 = m->r0, nb = m->nb, nrd = m->nrd;
     const uint32_t segstart_raw = lane < META_SEGS ? m->segstart[lane] : 0u, rs16 = lane < META_SEGS ? m->rs16[lane] : 0u;
     const uint64_t slab = t * rec.slab_cap;
-    uint32_t nh32 = rec.hash[slab + lane], npos = rec.j[slab + lane]; // (slab_cap >= 64: always inside the pool)
-    if (off_flags) return;
+    uint32_t nh32 = rec.hash[slab + lane], npos = rec.j[slab + lane]; // (slab_cap >= 64: always inside the pool)  [run-time k only]
     constexpr bool KFIX = KT > 0;
+    // compile-time k: the lane's three consecutive records, fetched under the assumptions that hold for all but a few tiles of a call -- 129 .. 192 minimizers
+    // (three per lane, below), in the tile's own slab -- so that the records travel with the first round trip instead of behind the tile's word
+    // (the addresses stay inside the pool whatever the slab holds: the overflow region and the arena's slack lie behind the last slab)
+    uint32_t sp_h0 = 0, sp_h1 = 0, sp_h2 = 0, sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // (scalars: as arrays the lambda below would keep them in scratch)
+    if constexpr (KFIX) {
+        const uint32_t *ph = rec.hash + slab + 3u * (uint32_t)lane, *pp = rec.j + slab + 3u * (uint32_t)lane;
+        sp_h0 = ph[0], sp_h1 = ph[1], sp_h2 = ph[2];
+        sp_p0 = pp[0], sp_p1 = pp[1], sp_p2 = pp[2];
+    }
+    if (off_flags) return;
     const uint32_t k = KFIX ? (uint32_t)KT : dz.k, K1 = k - 1;
     const unsigned long long ag0 = ((unsigned long long)dk_lane((uint32_t)(agw >> 32), 0) << 32) | dk_lane((uint32_t)agw, 0);
     const AggF ag = agg_unpack(ag0);
@@ -245,16 +254,16 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
     // km_off / mn_off of the reads that start in (t0, end of the tile]: the first nb inside, the rest exactly at the end
     if (lane >= 1 && (uint32_t)lane <= nrd) {
         dz.o_km_off[(uint64_t)r0 + lane] = (uint32_t)lane <= nb ? G + Wb : G + Wt;
-        if (dz.mn_capacity) dz.o_mn_off[(uint64_t)r0 + lane] = (uint32_t)lane <= nb ? Gmn + segstart : Gmn + N;
+        if (!FULL && dz.mn_capacity) dz.o_mn_off[(uint64_t)r0 + lane] = (uint32_t)lane <= nb ? Gmn + segstart : Gmn + N;
     }
     if (t == 0) // reads 0 .. r0 start at position 0
         for (uint64_t r = lane; r <= (uint64_t)r0; r += 64) {
             dz.o_km_off[r] = 0;
-            if (dz.mn_capacity) dz.o_mn_off[r] = 0;
+            if (!FULL && dz.mn_capacity) dz.o_mn_off[r] = 0;
         }
     if (t + 1 == n_tiles && lane == 0) {
         dz.o_km_off[n_reads] = G + Wt;
-        if (dz.mn_capacity) dz.o_mn_off[n_reads] = Gmn + N;
+        if (!FULL && dz.mn_capacity) dz.o_mn_off[n_reads] = Gmn + N;
     }
     if (N == 0) return;
     // ---- round trip 2: the up to k-1 minimizers of the continuing read that lie before the tile (lane q: the (q+1)-th counted
@@ -340,12 +349,21 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
         static_assert(64 * RB <= DK_STAGE_RECS, "a batch fits the staging area");
         int lane_b = lane; // (opaque per batch: what is derived from the lane index -- LDS addresses, offsets -- is otherwise hoisted out of the batch loop and spilled)
         asm volatile("" : "+v"(lane_b));
-        constexpr int S = ((int)KT - 1 + RB - 1) / RB; // lanes back that hold the k-1 minimizers before a lane_b's first
+        constexpr int S = ((int)KT - 1 + RB - 1) / RB; // lanes back that hold the k-1 minimizers before a lane's first
         constexpr int K1c = KT - 1;
-        const uint32_t i0 = b0 + (uint32_t)RB * (uint32_t)lane_b; // this lane_b's first minimizer
+        const uint32_t i0 = b0 + (uint32_t)RB * (uint32_t)lane_b; // this lane's first minimizer
         uint32_t h32[RB], pos[RB];
-        // the lane_b's records: RB consecutive entries of each array (reads past the tile's last record stay inside the pool: the arena keeps slack)
-        if (i0 < N) {
+        // the lane's records: RB consecutive entries of each array (reads past the tile's last record stay inside the pool: the arena keeps slack)
+        bool pre = false;
+        if constexpr (RB == 3) {
+            if (b0 == 0u && base == slab) { // (wave-uniform) what the first round trip fetched is what this batch wants
+                pre = true;
+                h32[0] = sp_h0, h32[1] = sp_h1, h32[2] = sp_h2;
+                pos[0] = sp_p0, pos[1] = sp_p1, pos[2] = sp_p2;
+            }
+        }
+        if (pre) {
+        } else if (i0 < N) {
 #pragma unroll
             for (int r = 0; r < RB; r++) {
                 h32[r] = rec.hash[base + i0 + r];
@@ -355,10 +373,10 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
 #pragma unroll
             for (int r = 0; r < RB; r++) h32[r] = pos[r] = 0u;
         }
-        // Z[u], u = -(k-1) .. RB-1: mixed hash (src/lib.rs:157-169) of the minimizer u places from the lane_b's first.  u >= 0: the lane_b's own; u < 0: they
-        // come down the lanes level by level (level s = the values of the lane_b s places back, slot r -> u = r - RB s), and every level is folded into the
+        // Z[u], u = -(k-1) .. RB-1: mixed hash (src/lib.rs:157-169) of the minimizer u places from the lane's first.  u >= 0: the lane's own; u < 0: they
+        // come down the lanes level by level (level s = the values of the lane s places back, slot r -> u = r - RB s), and every level is folded into the
         // first window's closed form  F = XOR rotl(Z[u], -u),  Rv = XOR rotl(Z[u], u + k - 1)  (src/lib.rs:275-288) as it arrives: one level is live at a time
-        uint32_t xl[RB], xh[RB], jj[RB];     // the lane_b's own
+        uint32_t xl[RB], xh[RB], jj[RB];     // the lane's own
         uint32_t cl[RB], ch[RB], cj[RB];     // the level in flight
         uint32_t outl[RB], outh[RB], js[RB]; // what the rolls and the records need later: Z[r - 1 - (k-1)] (r >= 1), j of Z[r - (k-1)]
         uint32_t jend[RB];
@@ -381,7 +399,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
         }
         auto rot_lo = [](uint32_t lo, uint32_t hi, int c) { return c ? __builtin_amdgcn_alignbit(lo, hi, 32 - c) : lo; }; // low word of rotl64(x, c), 0 <= c < 32
         auto rot_hi = [](uint32_t lo, uint32_t hi, int c) { return c ? __builtin_amdgcn_alignbit(hi, lo, 32 - c) : hi; };
-        // F / Rv of the lane_b's first window, terms folded two at a time with the three-input xor (v_bitop3_b32)
+        // F / Rv of the lane's first window, terms folded two at a time with the three-input xor (v_bitop3_b32)
         uint32_t fl = xl[0], fh = xh[0], rl = rot_lo(xl[0], xh[0], K1c), rh = rot_hi(xl[0], xh[0], K1c); // u = 0
         uint32_t pfl = 0, pfh = 0, prl = 0, prh = 0; // a term waiting for its partner
         bool have = false;                            // (compile-time once unrolled)
@@ -389,10 +407,10 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
         for (int sl = 1; sl <= S; sl++) {
 #pragma unroll
             for (int r = RB - 1; r >= 0; r--) {
-                const int m = RB * sl - r; // the level's slot r: Z[-m]; lane_b 0's value: the m-th minimizer before the batch
+                const int m = RB * sl - r; // the level's slot r: Z[-m]; lane 0's value: the m-th minimizer before the batch
                 unsigned long long cx = 0;
                 uint32_t cjv = 0;
-                if (m <= K1c) { // (every lane_b reads the same address: a broadcast)
+                if (m <= K1c) { // (every lane reads the same address: a broadcast)
                     cx = s_ring[w][K1c - m];
                     cjv = s_jcar[w][K1c - m];
                 }
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
                 bool deeper = false;
                 for (int s2 = sl; s2 <= S; s2++) deeper = deeper || RB * s2 - r <= K1c;
                 if (!deeper) continue;
-                cl[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)cx, (int)cl[r], 0x138, 0xf, 0xf, false); // wave_shr:1 -- lane_b 0 keeps "old"
+                cl[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)cx, (int)cl[r], 0x138, 0xf, 0xf, false); // wave_shr:1 -- lane 0 keeps "old"
                 ch[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(cx >> 32), (int)ch[r], 0x138, 0xf, 0xf, false);
                 bool j_deeper = false;
                 for (int s2 = sl; s2 <= S; s2++) j_deeper = j_deeper || (RB * s2 - r <= K1c && RB * s2 - r > K1c - RB);
@@ -417,7 +435,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
                     pfl = tfl, pfh = tfh, prl = trl, prh = trh;
                     have = true;
                 }
-                const int rr = K1c - m; // record rr of the lane_b starts its window at Z[-m]; record rr + 1 drops it when it rolls
+                const int rr = K1c - m; // record rr of the lane starts its window at Z[-m]; record rr + 1 drops it when it rolls
                 if (rr >= 0 && rr < RB) js[rr] = cj[r];
                 if (rr + 1 >= 1 && rr + 1 < RB) outl[rr + 1] = cl[r], outh[rr + 1] = ch[r];
             }
@@ -428,8 +446,8 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
             rl ^= prl;
             rh ^= prh;
         }
-        // (records whose window starts at one of the lane_b's own: k - 1 < RB never happens for k >= 5, RB <= 4)
-        static_assert(KT - 1 >= 4, "a window starts before the lane_b's own minimizers");
+        // (records whose window starts at one of the lane's own: k - 1 < RB never happens for k >= 5, RB <= 4)
+        static_assert(KT - 1 >= 4, "a window starts before the lane's own minimizers");
 #pragma unroll
         for (int r = 0; r < RB; r++) {
             if (r > 0) { // roll: the window loses Z[r-1-(k-1)] and takes Z[r]
