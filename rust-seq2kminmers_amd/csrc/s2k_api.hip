@@ -555,9 +555,9 @@ s2k_status enqueue(s2k_ctx *ctx) {
                     if (nokm) continue;
 #endif
                     S2K_TRY(launch_desc_scan(T0, T1, dz, d_scan, ctx->d_counts, s2), "tile word scan");
-                    // (the last chunk's k-min-mer kernel has the device to itself unless a chained context's next call follows)
-                    static const bool tail_coal = getenv("S2K_KM_TAIL_COAL") != nullptr;
-                    S2K_TRY(launch_desc_kminmers(T0, T1, n_tiles, n_reads, dz, rec, ctx->d_counts, s2, tail_coal && ch + 1 == n_chunks && !chained), "k-min-mer kernel");
+                    // (the last chunk's k-min-mer kernel has the device to itself unless a chained context's next call follows: staged stores,
+                    // +0.3 % for an unchained call, profiles/r06_chunks_prio_sweep.txt)
+                    S2K_TRY(launch_desc_kminmers(T0, T1, n_tiles, n_reads, dz, rec, ctx->d_counts, s2, ch + 1 == n_chunks && !chained), "k-min-mer kernel");
                 }
                 S2K_TRY(hipEventRecord(ctx->tiles_done, st), "event");
                 ctx->tiles_done_valid = true;
@@ -1337,7 +1337,7 @@ s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_
     Arena a{nullptr, 0, 0};
     uint32_t *cnt = nullptr, *blk_cnt = nullptr;
     uint64_t *tmp = nullptr, *blk_off = nullptr, *blk_tmp = nullptr, *read_c0 = nullptr;
-    uint32_t *seg_index = nullptr;
+    uint32_t *seg_index = nullptr, *lb_ws = nullptr;
     for (int pass = 0; pass < 2; pass++) {
         a.off = 0;
         cnt = a.take<uint32_t>(n_reads + 1);
@@ -1348,11 +1348,34 @@ s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_
             blk_tmp = a.take<uint64_t>(scan_tmp_bytes(nblk) / sizeof(uint64_t) + 1);
             read_c0 = a.take<uint64_t>(n_reads + 1);
             seg_index = a.take<uint32_t>(hpc_segment_index_words(n_bases));
+            lb_ws = a.take<uint32_t>(hpc_single_pass_words(n_bases));
         }
         if (pass == 0) {
             S2K_TRY(ctx->ws.ensure(a.off + 256), "workspace allocation");
             a.base = (char *)ctx->ws.p;
         }
+    }
+    // Two passes (default): the runs of every read counted first, then scanned (rounds 3-5).  One pass (S2K_HPC_SINGLE_PASS=1, round 6): every segment
+    // finds its first output slot by a decoupled look-back over the run-head counts of the segments before it -- bit-exact (tools/fuzz_hpc.py) and
+    // 1.7-2.1 x SLOWER on MI355X: a block's prefix can only be formed behind its predecessors', and words published on one XCD reach the others through
+    // memory, so the prefixes spread over the 488 k blocks of 2 Gbp at that latency whatever the window (64 words per look: 4.58 ms; 256: 5.64 ms;
+    // two passes: 2.66 ms -- profiles/r06_hpc_single_pass_*.txt).  Kept selectable, not used.
+    static const bool single_pass_env = getenv("S2K_HPC_SINGLE_PASS") != nullptr;
+    bool single_done = false;
+    if (seg_path && single_pass_env) {
+        uint32_t *fail_word = nullptr;
+        S2K_TRY(launch_hpc_single_pass(d_bases, d_read_off, n_reads, n_bases, lb_ws, d_hpc_off, d_hpc, d_pos, capacity, &fail_word, ctx->stream, rle),
+                "hpc single-pass kernels");
+        uint32_t failed = 0;
+        uint64_t total1 = 0;
+        S2K_TRY(hipMemcpyAsync(&failed, fail_word, sizeof failed, hipMemcpyDeviceToHost, ctx->stream), "D2H");
+        S2K_TRY(hipMemcpyAsync(&total1, d_hpc_off + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H");
+        S2K_TRY(hipStreamSynchronize(ctx->stream), "sync");
+        if (!failed) {
+            if (n_runs) *n_runs = total1;
+            return total1 > capacity && (d_hpc || d_pos) ? S2K_ERR_CAPACITY : S2K_OK;
+        }
+        (void)single_done;
     }
     if (seg_path) {
         S2K_TRY(launch_read_run_counts(d_bases, d_read_off, n_reads, n_bases, blk_cnt, blk_off, blk_tmp, cnt, read_c0, ctx->stream, rle),

@@ -246,6 +246,12 @@ hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off
 hipError_t launch_hpc_segments(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                                const uint64_t *hpc_off, const uint64_t *blk_off, const uint64_t *read_c0, uint32_t *seg_index, uint8_t *o_hpc,
                                uint32_t *o_pos, uint64_t capacity, hipStream_t st, bool rle = false);
+// The same outputs (hpc_off of every read included) in ONE pass over the bases: the segments' first output slots by a decoupled look-back over the
+// blocks' run-head counts (s2k_hpc_seg.hip).  ws: hpc_single_pass_words(n_bases) 32-bit words, 8-byte aligned; *fail_word (inside ws) is non-zero
+// afterwards when a look-back gave up (bounded polls): then the outputs are incomplete and the two-pass path above must be run.
+size_t hpc_single_pass_words(uint64_t n_bases);
+hipError_t launch_hpc_single_pass(const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint32_t *ws, uint64_t *o_hpc_off,
+                                  uint8_t *o_hpc, uint32_t *o_pos, uint64_t capacity, uint32_t **fail_word, hipStream_t st, bool rle = false);
 size_t hpc_segment_index_words(uint64_t n_bases); // uint32 words of seg_index (8-byte aligned workspace: per segment its first output slot, the read that holds its first byte and where that read starts)
 
 // read_off[0] == 0, non-decreasing, read_off[n_reads] == n_bases, no read longer than 2^32 - 2: anything else sets BAD_*

@@ -19,6 +19,9 @@ for mode in hpc regular; do
 done
 # the headline configuration itself (two chained contexts): kernel stats + trace, so that chunks x kernel time <= ms_per_step can be checked for `value`
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/hpc2ctx/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --mode hpc --contexts 2 --no-other-mode --no-cpu-baseline --no-end-to-end --verify-reads 0 > $out/hpc2ctx.stats.log 2>&1 || echo "stats pass failed (two contexts)"
+# the same two commands unprofiled, on this box: what the profiler itself costs
+python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --mode hpc --contexts 1 --no-other-mode --no-cpu-baseline --no-end-to-end --verify-reads 0 > $out/hpc.unprofiled.log 2>&1
+python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --mode hpc --contexts 2 --no-other-mode --no-cpu-baseline --no-end-to-end --verify-reads 0 > $out/hpc2ctx.unprofiled.log 2>&1
 python3 - <<PY
 import csv, glob, json, collections, os
 out = "$out"
@@ -82,7 +85,61 @@ with open(out + "/hpc2ctx_kernel_stats.csv", "w") as o:
     for r in rows:
         n = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
         o.write('"%s",%s,%s,%s,%s\n' % (n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
+# ---- round 6: statistics over the TIMED launches only (the warm-up launches of a run are slower and do not belong in the average), the kernel timeline of
+#      the last two chained calls, and the profiler's own overhead (the same command unprofiled, on the same box, see below)
+def trace_rows(d):
+    ev = []
+    for f in glob.glob(out + "/%s/stats/*/*kernel_trace.csv" % d):
+        for r in csv.DictReader(open(f)):
+            n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void s2k::", "").replace("s2k::", "")
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n))
+    return sorted(ev)
+def bench_line(log):
+    try:
+        return json.loads([l for l in open(log) if l.startswith("{")][-1])
+    except Exception:
+        return None
+with open(out + "/timed_kernel_stats.txt", "w") as o:
+    for d, steps, warm in (("hpc", 5, 2), ("regular", 5, 2), ("hpc2ctx", 6, 2)):
+        ev = trace_rows(d)
+        bl = bench_line(out + "/%s.stats.log" % d)
+        o.write("== %s: rocprofv3 --kernel-trace of bench.py --steps %d --warmup %d; launches of the TIMED steps only (the last %d of %d calls of a kernel per call)\n" % (d, steps, warm, steps, steps + warm))
+        if bl:
+            o.write("   bench line of the profiled run: ms_per_step %.3f (value %.1f), one_context %s\n" % (bl["ms_per_step"], bl["value"], bl.get("one_context")))
+        by = collections.defaultdict(list)
+        for st, en, n in ev:
+            if "tile_minimizer" in n or "desc_kminmer" in n or "desc_scan" in n or "read_table" in n or "finalize" in n:
+                by[n].append((st, en))
+        for n in sorted(by):
+            L = by[n]
+            if d == "hpc2ctx":  # the one-context leg comes first in this process: (steps + warm) calls; then the chained legs
+                per1 = len(L) // 1  # (reported as they are: the chained calls are the LAST steps x chunks launches)
+            k = len(L) * steps // (steps + warm) if d != "hpc2ctx" else None
+            if d == "hpc2ctx":
+                # one-context calls: 6 chunks each, (steps + warm) of them; chained: 3 chunks each, (steps + warm') of them -- take the last steps x 3
+                chunks2 = 3 if "tile_minimizer" in n or "desc_kminmer" in n else (15 if "desc_scan" in n else 1)
+                k = min(len(L), steps * chunks2)
+            T = L[-k:] if k else L
+            durs = [(en - st) / 1e3 for st, en in T]
+            o.write("   %-60s timed launches %4d  avg %9.1f us  min %9.1f  max %9.1f  (all %d launches avg %.1f us)\n" % (
+                n[-60:], len(T), sum(durs) / len(durs), min(durs), max(durs), len(L), sum((en - st) / 1e3 for st, en in L) / len(L)))
+    # timeline of the last two chained calls
+    ev = trace_rows("hpc2ctx")
+    mins = [e for e in ev if "tile_minimizer" in e[2]]
+    if len(mins) >= 7:
+        t0 = mins[-6][0]
+        o.write("== hpc2ctx: kernel timeline of the last two chained calls (us from the first minimizer kernel of the second-to-last call)\n")
+        for st, en, n in ev:
+            if st >= t0 and ("tile_minimizer" in n or "desc_kminmer" in n or "finalize" in n or "read_table" in n):
+                tag = "MIN" if "tile_minimizer" in n else "KMM" if "desc_kminmer" in n else "FIN" if "finalize" in n else "RT "
+                o.write("   %s start %9.1f end %9.1f dur %8.1f\n" % (tag, (st - t0) / 1e3, (en - t0) / 1e3, (en - st) / 1e3))
+    # profiler overhead: the unprofiled runs of the same commands (written by the shell below)
+    for d in ("hpc", "hpc2ctx"):
+        a, b = bench_line(out + "/%s.stats.log" % d), bench_line(out + "/%s.unprofiled.log" % d)
+        if a and b:
+            o.write("== profiler overhead (%s): ms_per_step %.3f under rocprofv3 --kernel-trace --stats, %.3f unprofiled on the same box (one_context %s / %s)\n" % (
+                d, a["ms_per_step"], b["ms_per_step"], a.get("one_context", {}).get("ms_per_step"), b.get("one_context", {}).get("ms_per_step")))
 json.dump(res["hpc"], open(out + "/traffic_hpc.json", "w"), indent=1)
 json.dump(res["regular"], open(out + "/traffic_regular.json", "w"), indent=1)
 PY
-cat $out/hpc_kernel_stats.csv; cat $out/hpc_pmc_summary.txt | head -60
+cat $out/hpc_kernel_stats.csv; cat $out/hpc_pmc_summary.txt | head -60; cat $out/timed_kernel_stats.txt
