@@ -30,15 +30,36 @@ namespace {
 // drain the D2H ring (measured: 1.3 GB of results took 104 ms to land instead of 35), so blocks given back by
 // s2k_result_free are kept by the context that made them and reused by its next call; new blocks are 2 MiB-aligned and
 // advised to transparent huge pages.  The pool outlives the context while results still refer to it.
+// Round 6: large blocks are PINNED (hipHostRegister) when they are made, so that the drain of a sub-batch is a plain DMA straight into the caller-visible
+// arrays -- no staging ring, no copy threads: the 16 CPUs of a 1-GPU job are left to the packing of the next sub-batch's bases.  Pinning costs ~0.1 s per
+// GB once; the pool keeps the blocks across calls.  A block that cannot be pinned (the budget below, a refusal by the driver) is drained through the
+// staging ring as before.  S2K_PIN_RESULTS=0 turns it off.
 struct HostPool {
     struct Blk {
         void *p;
         size_t cap;
+        bool pinned;
     };
     std::mutex mu;
     std::vector<Blk> idle;
-    static constexpr size_t kKeep = 18; // two calls' worth of arrays
-    void *get(size_t bytes, size_t *cap) {
+    size_t pinned_bytes = 0;                          // of all blocks this pool has made and not freed
+    static constexpr size_t kKeep = 18;               // two calls' worth of arrays
+    static constexpr size_t kPinBudget = 24ull << 30; // pinned host memory this pool may hold
+    static bool pin_enabled() {
+        static const bool on = !(getenv("S2K_PIN_RESULTS") && atoi(getenv("S2K_PIN_RESULTS")) == 0);
+        return on;
+    }
+    void release(const Blk &b) {
+        if (!b.p) return;
+        if (b.pinned) {
+            (void)hipHostUnregister(b.p);
+            std::lock_guard<std::mutex> lk(mu);
+            pinned_bytes -= b.cap;
+        }
+        free(b.p);
+    }
+    void *get(size_t bytes, size_t *cap, bool *pinned = nullptr) {
+        if (pinned) *pinned = false;
         if (bytes == 0) bytes = 1;
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -49,36 +70,60 @@ struct HostPool {
                 Blk b = idle[best];
                 idle.erase(idle.begin() + (long)best);
                 *cap = b.cap;
+                if (pinned) *pinned = b.pinned;
                 return b.p;
             }
         }
         void *q = nullptr;
         size_t want = bytes;
+        bool pin = false;
         if (bytes >= (4u << 20)) {
             want = (bytes + bytes / 16 + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
             if (posix_memalign(&q, 2u << 20, want) != 0) q = nullptr;
             if (q) (void)madvise(q, want, MADV_HUGEPAGE);
+            if (q && pin_enabled()) {
+                bool room;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    room = pinned_bytes + want <= kPinBudget;
+                    if (room) pinned_bytes += want;
+                }
+                if (room) {
+                    pin = hipHostRegister(q, want, hipHostRegisterPortable) == hipSuccess;
+                    if (!pin) {
+                        (void)hipGetLastError();
+                        std::lock_guard<std::mutex> lk(mu);
+                        pinned_bytes -= want;
+                    }
+                }
+            }
         } else {
             q = malloc(want);
         }
         *cap = q ? want : 0;
+        if (pinned) *pinned = q && pin;
+        if (!pinned && pin) { // (a caller that does not ask cannot hand the flag back: keep the accounting right)
+            (void)hipHostUnregister(q);
+            std::lock_guard<std::mutex> lk(mu);
+            pinned_bytes -= want;
+        }
         return q;
     }
-    void put(void *q, size_t cap) {
+    void put(void *q, size_t cap, bool pinned = false) {
         if (!q) return;
-        void *drop = nullptr;
+        Blk drop{nullptr, 0, false};
         {
             std::lock_guard<std::mutex> lk(mu);
-            idle.push_back(Blk{q, cap});
+            idle.push_back(Blk{q, cap, pinned});
             if (idle.size() > kKeep) { // drop the smallest
                 size_t m = 0;
                 for (size_t i = 1; i < idle.size(); i++)
                     if (idle[i].cap < idle[m].cap) m = i;
-                drop = idle[m].p;
+                drop = idle[m];
                 idle.erase(idle.begin() + (long)m);
             }
         }
-        free(drop);
+        release(drop);
     }
     size_t trim() { // s2k_trim: give every idle block back to the allocator
         std::vector<Blk> drop;
@@ -89,12 +134,15 @@ struct HostPool {
         size_t bytes = 0;
         for (Blk &b : drop) {
             bytes += b.cap;
-            free(b.p);
+            release(b);
         }
         return bytes;
     }
     ~HostPool() {
-        for (Blk &b : idle) free(b.p);
+        for (Blk &b : idle) {
+            if (b.pinned) (void)hipHostUnregister(b.p);
+            free(b.p);
+        }
     }
 };
 
@@ -102,13 +150,14 @@ struct HostOwner { // backing store of one s2k_result (no zero fill -- the array
     std::shared_ptr<HostPool> pool;
     void *p[9] = {};
     size_t cap[9] = {};
+    bool pinned[9] = {};
     explicit HostOwner(std::shared_ptr<HostPool> hp) : pool(std::move(hp)) {}
     template <typename T> T *take(int slot, uint64_t n) {
-        p[slot] = pool->get((size_t)n * sizeof(T), &cap[slot]);
+        p[slot] = pool->get((size_t)n * sizeof(T), &cap[slot], &pinned[slot]);
         return (T *)p[slot];
     }
     ~HostOwner() {
-        for (int i = 0; i < 9; i++) pool->put(p[i], cap[i]);
+        for (int i = 0; i < 9; i++) pool->put(p[i], cap[i], pinned[i]);
     }
 };
 
@@ -991,12 +1040,14 @@ struct Drain { // the s2k_result under construction and the thread that fills it
 
     bool grow(int slot, size_t es, uint64_t used, uint64_t want) {
         size_t ncap = 0;
-        void *q = ow->pool->get((size_t)want * es, &ncap);
+        bool npin = false;
+        void *q = ow->pool->get((size_t)want * es, &ncap, &npin);
         if (!q) return false;
         if (used) memcpy(q, ow->p[slot], (size_t)used * es);
-        ow->pool->put(ow->p[slot], ow->cap[slot]);
+        ow->pool->put(ow->p[slot], ow->cap[slot], ow->pinned[slot]);
         ow->p[slot] = q;
         ow->cap[slot] = ncap;
+        ow->pinned[slot] = npin;
         return true;
     }
     bool ensure(uint64_t nk, uint64_t nm) { // the estimate of the whole call was too small (rare): grow, keep what is there
@@ -1028,16 +1079,22 @@ struct Drain { // the s2k_result under construction and the thread that fills it
         }
         hipStream_t s = ctx->s_out;
         s2k::HostStager &hs = ctx->stager_out;
-        hipError_t e = hs.d2h(res->km_off + b.r_lo, b.o.km_off, (b.n_reads + 1) * 8, s);
-        if (e == hipSuccess) e = hs.d2h(res->hash + used_k, b.o.hash, nk * 8, s);
-        if (e == hipSuccess) e = hs.d2h(res->start + used_k, b.o.start, nk * 4, s);
-        if (e == hipSuccess) e = hs.d2h(res->end + used_k, b.o.end, nk * 4, s);
-        if (e == hipSuccess) e = hs.d2h(res->rev + used_k, b.o.rev, nk, s);
+        // an array whose block is pinned takes its part by DMA, asynchronously (one wait for all of them below); the others go through the staging ring
+        auto down = [&](int slot, void *dst, const void *src, size_t bytes) -> hipError_t {
+            if (bytes == 0) return hipSuccess;
+            if (ow->pinned[slot]) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+            return hs.d2h(dst, src, bytes, s);
+        };
+        hipError_t e = down(0, res->km_off + b.r_lo, b.o.km_off, (b.n_reads + 1) * 8);
+        if (e == hipSuccess) e = down(1, res->hash + used_k, b.o.hash, nk * 8);
+        if (e == hipSuccess) e = down(2, res->start + used_k, b.o.start, nk * 4);
+        if (e == hipSuccess) e = down(3, res->end + used_k, b.o.end, nk * 4);
+        if (e == hipSuccess) e = down(4, res->rev + used_k, b.o.rev, nk);
         if (want_mn) {
-            if (e == hipSuccess) e = hs.d2h(res->mn_off + b.r_lo, b.o.mn_off, (b.n_reads + 1) * 8, s);
-            if (e == hipSuccess) e = hs.d2h(res->mn_j + used_m, b.o.mn_j, nm * 4, s);
-            if (e == hipSuccess) e = hs.d2h(res->mn_jend + used_m, b.o.mn_jend, nm * 4, s);
-            if (e == hipSuccess) e = hs.d2h(res->mn_hash + used_m, b.o.mn_hash, nm * 4, s);
+            if (e == hipSuccess) e = down(5, res->mn_off + b.r_lo, b.o.mn_off, (b.n_reads + 1) * 8);
+            if (e == hipSuccess) e = down(6, res->mn_j + used_m, b.o.mn_j, nm * 4);
+            if (e == hipSuccess) e = down(7, res->mn_jend + used_m, b.o.mn_jend, nm * 4);
+            if (e == hipSuccess) e = down(8, res->mn_hash + used_m, b.o.mn_hash, nm * 4);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) {

@@ -217,11 +217,11 @@ size_t pack2_scalar(const uint8_t *src, size_t n, uint8_t *dst, Exc *exc, size_t
 }
 
 __attribute__((target("avx2,bmi2"))) size_t pack2_avx2(const uint8_t *src, size_t n, uint8_t *dst, Exc *exc, size_t cap,
-                                                        uint32_t chunk_off) {
+                                                        uint32_t chunk_off, size_t ne0) {
     const __m256i lut = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0,
                                          0, 0, 0);
     const __m256i m6 = _mm256_set1_epi8(6);
-    size_t ne = 0, i = 0;
+    size_t ne = ne0, i = 0;
     for (; i + 32 <= n; i += 32) {
         const __m256i v = _mm256_loadu_si256((const __m256i *)(src + i));
         const __m256i c2 = _mm256_and_si256(v, m6);                    // code << 1
@@ -247,10 +247,11 @@ __attribute__((target("avx2,bmi2"))) size_t pack2_avx2(const uint8_t *src, size_
 // then 1, 16 per word pair: c0 + 4 c1 + 16 c2 + 64 c3 <= 255) and the sixteen dwords narrowed to sixteen bytes (vpmovdb).  ~10 instructions per 64
 // bytes against four pext + extracts per 32: the threads of a 1-GPU job (16 of the host's) pack at the rate they can read pageable memory.
 // A 64-byte group with any other byte goes through the scalar routine (its exceptions are listed); groups of clean text never touch it.
-__attribute__((target("avx512f,avx512bw"))) size_t pack2_avx512(const uint8_t *src, size_t n, uint8_t *dst, Exc *exc, size_t cap, uint32_t chunk_off) {
+__attribute__((target("avx512f,avx512bw"))) size_t pack2_avx512(const uint8_t *src, size_t n, uint8_t *dst, Exc *exc, size_t cap, uint32_t chunk_off,
+                                                                size_t ne0) {
     const __m512i lut = _mm512_broadcast_i32x4(_mm_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0));
     const __m512i m3 = _mm512_set1_epi8(3), w14 = _mm512_set1_epi16(0x0401), w116 = _mm512_set1_epi32(0x00100001);
-    size_t ne = 0, i = 0;
+    size_t ne = ne0, i = 0;
     for (; i + 64 <= n; i += 64) {
         const __m512i v = _mm512_loadu_si512((const void *)(src + i));
         const __m512i code = _mm512_and_si512(_mm512_srli_epi16(v, 1), m3); // (b >> 1) & 3 per byte: the bits a 16-bit shift drags in are masked off
@@ -267,13 +268,14 @@ __attribute__((target("avx512f,avx512bw"))) size_t pack2_avx512(const uint8_t *s
     return ne;
 }
 
-size_t pack2(const uint8_t *src, size_t n, uint8_t *dst, Exc *exc, size_t cap, uint32_t chunk_off) {
+// ne0: exceptions already in exc[] (a slice packed piece by piece)
+size_t pack2(const uint8_t *src, size_t n, uint8_t *dst, Exc *exc, size_t cap, uint32_t chunk_off, size_t ne0 = 0) {
     static const int level = getenv("S2K_PACK_ISA") ? atoi(getenv("S2K_PACK_ISA")) // (A/B and tests: 0 scalar, 1 AVX2, 2 AVX-512)
                              : (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw")) ? 2
                              : (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2")) ? 1 : 0;
-    if (level >= 2 && __builtin_cpu_supports("avx512bw")) return pack2_avx512(src, n, dst, exc, cap, chunk_off);
-    if (level >= 1 && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2")) return pack2_avx2(src, n, dst, exc, cap, chunk_off);
-    return pack2_scalar(src, n, dst, exc, cap, chunk_off, 0);
+    if (level >= 2 && __builtin_cpu_supports("avx512bw")) return pack2_avx512(src, n, dst, exc, cap, chunk_off, ne0);
+    if (level >= 1 && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2")) return pack2_avx2(src, n, dst, exc, cap, chunk_off, ne0);
+    return pack2_scalar(src, n, dst, exc, cap, chunk_off, ne0);
 }
 
 // 16 bases per thread: 4 packed bytes -> 16 ASCII bytes ("ACTG"[code])
@@ -336,21 +338,26 @@ hipError_t HostStager::packed_impl(void *dst_dev, const uint8_t *src, const std:
         std::atomic<bool> overflow{false}, failed{false};
         // every slice packs its part and keeps its exceptions in the matching part of the second half: [count u64][entries]
         pool_->slices(n, [&](size_t b, size_t en) {
-            const uint8_t *from;
-            if (src) {
-                from = src + off + b;
-            } else {
-                thread_local std::vector<uint8_t> scratch;
-                if (scratch.size() < en - b) scratch.resize(en - b);
-                if (!(*fill)((char *)scratch.data(), off + b, en - b)) {
-                    failed = true;
-                    return;
-                }
-                from = scratch.data();
-            }
             char *region = pin + kHalf + b / 4;
             const size_t cap = (en - b) / 4 >= 16 ? ((en - b) / 4 - 8) / sizeof(Exc) : 0;
-            const size_t ne = pack2(from, en - b, (uint8_t *)pin + b / 4, (Exc *)(region + 8), cap, (uint32_t)b);
+            size_t ne = 0;
+            if (src) {
+                ne = pack2(src + off + b, en - b, (uint8_t *)pin + b / 4, (Exc *)(region + 8), cap, (uint32_t)b);
+            } else {
+                // a produced source (a file): piece by piece through a scratch buffer that stays in the core's L2 -- read 256 KiB, pack them, read the next --,
+                // so that the text crosses DRAM once (page cache -> L2) instead of three times (round 6; rounds 2-5 read the whole 4 MiB slice first)
+                constexpr size_t kPiece = 256u << 10;
+                thread_local std::vector<uint8_t> scratch;
+                if (scratch.size() < kPiece) scratch.resize(kPiece);
+                for (size_t o = b; o < en && ne != SIZE_MAX; o += kPiece) {
+                    const size_t len = en - o < kPiece ? en - o : kPiece;
+                    if (!(*fill)((char *)scratch.data(), off + o, len)) {
+                        failed = true;
+                        return;
+                    }
+                    ne = pack2(scratch.data(), len, (uint8_t *)pin + o / 4, (Exc *)(region + 8), cap, (uint32_t)o, ne);
+                }
+            }
             if (ne == SIZE_MAX) overflow = true;
             else memcpy(region, &ne, 8);
         });

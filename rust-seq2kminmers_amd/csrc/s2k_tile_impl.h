@@ -355,28 +355,33 @@ __device__ __forceinline__ void close_piece(uint32_t &bits, uint32_t (&raw)[5]) 
 // l-mer at position p = s - L is complete, so it is tested and then rolled forward with OUT[p], IN[s].
 // W[] holds the lane's stream as dwords (piece j = W[4j .. 4j+3], read one piece ahead of its first use); only the
 // ~12 dwords between the outgoing and the incoming base are live at any time.
-template <int L, int T, int LA, bool W2, int S>
+#ifdef HX_PIECE4 // (tools/experiments/hash_stream_bench.hip: the loop below with P4 forced on)
+constexpr bool HX_P4_DEFAULT = true;
+#else
+constexpr bool HX_P4_DEFAULT = false;
+#endif
+// P4: the lane's stream comes from GLOBAL memory (stream_minimizer_kernel): four pieces = 64 bytes per lane at a time, so that a lane's loads of one 128-byte
+// line follow each other (16 bytes at a time the strided access bounds the loop, profiles/r04_hash_loop_without_tile_buffer.txt)
+template <int L, int T, int LA, bool W2, bool P4, int S>
 __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * ((T + L + 15) / 16)], uint32_t (&A)[T + L],
                                            uint2 (&EI)[T + L], uint2 (&EO)[T], uint32_t &fh, uint32_t &rh, uint32_t (&caps)[NPC], uint32_t (&raw)[5],
                                            uint32_t &bits, uint32_t bound, int np) {
     if constexpr (S < T + L - 1) {
-#ifdef HX_PIECE4 // (tools/experiments/hash_stream_bench.hip only: four pieces = 64 bytes per lane at a time, so that a lane's loads of one 128-byte line follow each other)
-        if constexpr (S % 64 == 0) {
+        if constexpr (P4) {
+            if constexpr (S % 64 == 0) {
 #pragma unroll
-            for (int pj = 0; pj < 4; pj++) {
-                constexpr int PB = S / 16 + 4;
-                if (PB + pj < (T + L + 15) / 16) {
-                    const uint4 v = src[PB + pj];
-                    W[4 * (PB + pj)] = v.x; W[4 * (PB + pj) + 1] = v.y; W[4 * (PB + pj) + 2] = v.z; W[4 * (PB + pj) + 3] = v.w;
+                for (int pj = 0; pj < 4; pj++) {
+                    constexpr int PB = S / 16 + 4;
+                    if (PB + pj < (T + L + 15) / 16) {
+                        const uint4 v = src[PB + pj];
+                        W[4 * (PB + pj)] = v.x; W[4 * (PB + pj) + 1] = v.y; W[4 * (PB + pj) + 2] = v.z; W[4 * (PB + pj) + 3] = v.w;
+                    }
                 }
             }
-        }
-#else
-        if constexpr (S % 16 == 0 && S / 16 + 2 < (T + L + 15) / 16) { // piece S/16+2: its first base enters >= 16 steps from now
+        } else if constexpr (S % 16 == 0 && S / 16 + 2 < (T + L + 15) / 16) { // piece S/16+2: its first base enters >= 16 steps from now
             const uint4 v = src[S / 16 + 2];
             W[4 * (S / 16 + 2)] = v.x; W[4 * (S / 16 + 2) + 1] = v.y; W[4 * (S / 16 + 2) + 2] = v.z; W[4 * (S / 16 + 2) + 3] = v.w;
         }
-#endif
         // seeds are fetched LA steps ahead of their use, a group of LA at a time
         if constexpr (S % LA == 0) {
             __builtin_amdgcn_sched_barrier(0); // keep the scheduler from hoisting later groups' look-ups (register pressure)
@@ -426,7 +431,7 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * (
                 if (P / 16 + 1 >= np) return; // wave-uniform: the (compacted) tile is shorter than 144 bases per lane
             }
         }
-        hash_steps<L, T, LA, W2, S + 1>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
+        hash_steps<L, T, LA, W2, P4, S + 1>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
     } else { // last position: test only, nothing left to roll into
         const uint32_t hv = fh < rh ? fh : rh;
         hit_track(hv, bound, caps[(T - 1) / CAPP], bits);
@@ -434,7 +439,7 @@ __device__ __forceinline__ void hash_steps(const uint4 *src, uint32_t (&W)[4 * (
     }
 }
 
-template <int L, int LA, bool W2>
+template <int L, int LA, bool W2, bool P4 = HX_P4_DEFAULT>
 __device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t bound, int lane, int np, uint32_t (&caps)[NPC],
                                                  uint32_t (&raw)[5]) {
     constexpr int T = TILE_T;
@@ -446,11 +451,11 @@ __device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t boun
         const uint4 v0 = src[0], v1 = src[1];
         W[0] = v0.x; W[1] = v0.y; W[2] = v0.z; W[3] = v0.w;
         W[4] = v1.x; W[5] = v1.y; W[6] = v1.z; W[7] = v1.w;
-#ifdef HX_PIECE4
-        const uint4 v2 = src[2], v3 = src[3];
-        W[8] = v2.x; W[9] = v2.y; W[10] = v2.z; W[11] = v2.w;
-        W[12] = v3.x; W[13] = v3.y; W[14] = v3.z; W[15] = v3.w;
-#endif
+        if constexpr (P4) {
+            const uint4 v2 = src[2], v3 = src[3];
+            W[8] = v2.x; W[9] = v2.y; W[10] = v2.z; W[11] = v2.w;
+            W[12] = v3.x; W[13] = v3.y; W[14] = v3.z; W[15] = v3.w;
+        }
     }
     uint32_t A[T + L]; // LDS byte offset of each base's table entries: formed when the base enters, reused when it leaves
     uint2 EI[T + L], EO[T];
@@ -459,7 +464,7 @@ __device__ __forceinline__ void hash_loop_static(const uint8_t *D, uint32_t boun
 #pragma unroll
     for (int i = 0; i < LA; i++) EI[i] = (W2 && i % 2 == 0 && i + 1 < L) ? seed_pair<WARM_OFF>(A[i]) : seed_pair<0>(A[i]);
     uint32_t fh = 0, rh = 0, bits = 0;
-    hash_steps<L, T, LA, W2, 0>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
+    hash_steps<L, T, LA, W2, P4, 0>(src, W, A, EI, EO, fh, rh, caps, raw, bits, bound, np);
 }
 
 // Same loop for a run-time l (1 .. 64; only l values without a static instantiation come here), unrolled like the static one.  The
@@ -1996,6 +2001,175 @@ __global__ __launch_bounds__(64 * tw<HPC>(), waves_per_simd<HPC>()) void tile_mi
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Regular family WITHOUT a tile buffer (round 6; descriptor path, compile-time l, tiles that lie wholly inside the stream).
+// The 16-wave block of tile_minimizer_kernel<L, false> owns all 160 KiB of a CU's LDS for its tile buffers: four waves per SIMD is all the LDS
+// allows, and nothing -- the k-min-mer kernel least of all -- fits beside it.  A Regular lane hashes 144 + l CONSECUTIVE raw bytes: it can take them
+// straight from global memory, 64 bytes (four pieces) at a time so that its accesses to one 128-byte line follow each other -- the hash loop alone
+// runs at the LDS-staged loop's rate at every occupancy that way (profiles/r04_hash_loop_without_tile_buffer.txt).  What is left in LDS is the
+// dense phase's hit list (< 1 KiB per wave): the registers set the occupancy, and the k-min-mer kernel of the chunk before runs BESIDE this kernel as
+// it does beside the Hpc one.  The dense phase is the tiled kernel's own (dense_phase<L, false, true>); the bytes of the few hits whose hash must
+// be re-derived come from global memory again (L2).  The stream's last one or two tiles (no 128-byte look-ahead inside the stream) go to the
+// tiled kernel.
+// MEASURED (profiles/r06_stream.txt, 10 Gbp Regular): bit-exact, and slower than the tiled kernel in every arrangement -- four waves per SIMD, k-min-mer
+// stage behind it: 4.11 ms against the tiled kernel's 3.91 (the loop that ran alone at the LDS-staged rate does not inside the kernel); five waves
+// (two blocks of ten, 96 VGPRs): 5.3 ms; four waves with the k-min-mer kernel beside it in 4-8 chunks: 5.27-5.45 ms per step against 5.05.  So the
+// kernel is compiled only into builds made with -DS2K_STREAM_BUILD=1 (tools/ab/build_variant.sh) and selected there by S2K_STREAM_KERNEL=1; the
+// CPU tier keeps it compiling (tests/test_isa_invariants.py).
+// ------------------------------------------------------------------------------------------------
+#ifndef S2K_STREAM_BUILD
+#define S2K_STREAM_BUILD 0
+#endif
+#if S2K_STREAM_BUILD
+#ifndef S2K_STREAM_DEFAULT
+#define S2K_STREAM_DEFAULT 0 // 1: the Regular family's descriptor path uses stream_minimizer_kernel unless S2K_STREAM_KERNEL=0
+#endif
+#ifndef S2K_STREAM_TW
+#define S2K_STREAM_TW 16 // waves per block
+#endif
+#ifndef S2K_STREAM_BPC
+#define S2K_STREAM_BPC 1 // blocks per CU (a block has at most 16 waves: five or six waves per SIMD take two blocks)
+#endif
+#ifndef S2K_STREAM_WPS
+#define S2K_STREAM_WPS ((S2K_STREAM_TW * S2K_STREAM_BPC + 3) / 4) // waves per SIMD the registers are budgeted for (more than the kernel's own: room for the k-min-mer kernel's beside them)
+#endif
+constexpr int STREAM_TW = S2K_STREAM_TW, STREAM_BPC = S2K_STREAM_BPC, STREAM_WPS = S2K_STREAM_WPS;
+struct alignas(16) StreamLds { // per wave: what dense_phase keeps in LDS (see WaveLdsT)
+    uint16_t list[listcap<false>()];
+    uint16_t jobx[jobcap<false>()];
+    uint16_t jobslot[jobcap<false>()];
+    int16_t hb[NBL];
+    uint16_t rs16[NBL];
+};
+constexpr int stream_lds_bytes() { return SEED_TABLE_BYTES + STREAM_TW * (int)sizeof(StreamLds); }
+
+template <int L>
+__global__ __launch_bounds__(64 * STREAM_TW, STREAM_WPS) void stream_minimizer_kernel(
+    const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles /* full tiles only */,
+    const uint32_t *__restrict__ tile_read0, Sem sem, Records rec, uint64_t *pool_cursor, Counts *counts, unsigned long long *__restrict__ d_agg,
+    TileMeta *__restrict__ d_meta, uint32_t K1, uint64_t tile_begin) {
+    static_assert(L > 0, "compile-time l only");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint2 *tab = reinterpret_cast<uint2 *>(smem);
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap(); // the seed look-ups assume the tables at LDS address 0
+    const int lane0 = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int TW = STREAM_TW;
+    constexpr uint32_t l = (uint32_t)L;
+    for (int c = threadIdx.x; c < 256; c += 64 * TW) {
+        const uint32_t cc = c;
+        const uint32_t h = sem.simd_seeds ? seed_h_simd(cc) : seed_h_scalar(cc), r = sem.simd_seeds ? seed_rc_simd(cc) : seed_rc_scalar(cc);
+        tab[c] = make_uint2(h, rotl32(r, l - 1));
+        tab[256 + c] = make_uint2(rotl32(h, l), rotr32(r, 1));
+    }
+    __syncthreads(); // the only workgroup barrier; waves are independent from here on
+    StreamLds &S = *reinterpret_cast<StreamLds *>(smem + SEED_TABLE_BYTES + (size_t)w * sizeof(StreamLds));
+    const uint64_t n_waves = (uint64_t)gridDim.x * TW;
+    uint64_t t = tile_begin + (uint64_t)blockIdx.x * TW + w;
+    if (t >= n_tiles) return;
+    if (__builtin_amdgcn_readfirstlane((int)counts->bad_input)) return; // malformed read table: touch nothing
+    uint64_t stamp = 0;
+    ph_ptr_t ph = nullptr;
+    int lane = lane0;
+    // software pipeline over the wave's tiles as in tile_minimizer_kernel: the read-table entries of the next tile and the draw for the one after it
+    // are issued before the hash loop and looked at after it
+    uint32_t r0 = tile_read0[t], r1 = tile_read0[t + 1];
+    uint64_t bpos0, rs0;
+    {
+        const uint64_t bri = (uint64_t)r0 + 1 + lane;
+        bpos0 = bri <= n_reads ? read_off[bri] : ~0ull;
+        rs0 = read_off[r0];
+    }
+    uint64_t tn = t + n_waves, tnn = t + 2 * n_waves;
+    const uint64_t dyn0 = tile_begin + 3 * n_waves;
+    const uint32_t cur_g = (uint32_t)((blockIdx.x * TW + w + blockIdx.x / (TILE_CURSORS / 4)) % TILE_CURSORS); // (see tile_minimizer_kernel)
+    unsigned int *const cursors = (unsigned int *)(pool_cursor + 16);
+    uint32_t r0n = 0, r1n = 0;
+    if (tn < n_tiles) {
+        r0n = tile_read0[tn];
+        r1n = tile_read0[tn + 1];
+    }
+    bool lb_dead = false;
+    for (; t < n_tiles;) {
+        lane = lane0;
+        asm volatile("" : "+v"(lane)); // (nothing derived from the lane index is loop-invariant: see tile_minimizer_kernel)
+        const uint64_t t0 = t * (uint64_t)TILE_BASES;
+        const uint32_t cr0 = r0, cr1 = r1;
+        uint32_t took = 0;
+        if (lane == 0 && tnn < n_tiles) took = atomicAdd(&cursors[32 * cur_g], 1u);
+        uint64_t bposn = ~0ull, rs0n = 0;
+        uint32_t r0nn = 0, r1nn = 0;
+        const uint64_t brin = (uint64_t)r0n + 1 + lane;
+        uint32_t vzero = 0;
+        asm volatile("" : "+v"(vzero));
+        if (tn < n_tiles) {
+            bposn = read_off[brin <= n_reads ? brin : n_reads];
+            rs0n = read_off[(uint64_t)r0n + vzero];
+            if (tnn < n_tiles) {
+                r0nn = tile_read0[tnn + vzero];
+                r1nn = tile_read0[tnn + 1 + vzero];
+            }
+        }
+        uint32_t caps[NPC], raw[5];
+#pragma unroll
+        for (int g2 = 0; g2 < NPC; g2++) caps[g2] = 0;
+#pragma unroll
+        for (int g2 = 0; g2 < 5; g2++) raw[g2] = 0;
+        const uint8_t *D = bases + t0; // global memory: the tile and its look-ahead lie inside the stream
+        if (sem.enabled) hash_loop_static<L, REG_LA, false, true>(D, sem.bound_le, lane, TILE_T / 16, caps, raw);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the loads above had the whole hash loop to finish
+        if (brin > n_reads) bposn = ~0ull;
+        rs0n = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rs0n >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rs0n);
+        r0nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0nn);
+        r1nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)r1nn);
+        uint64_t drawn = ~0ull;
+        if (tnn < n_tiles) drawn = dyn0 + cur_g + (uint64_t)TILE_CURSORS * (uint32_t)__builtin_amdgcn_readfirstlane((int)took);
+        int lane_d = lane;
+        asm volatile("" : "+v"(lane_d));
+        uint64_t base = 0;
+        auto no_issue = [](uint32_t, uint64_t) {};
+        (void)dense_phase<L, false, true>(no_issue, S, D, tab, read_off, n_reads, t, t0, (uint32_t)TILE_BASES, (uint32_t)TILE_BASES, 0u, (uint32_t)TILE_T, 7282u, l,
+                                          cr0, cr1, bpos0, rs0, lane_d, rec, pool_cursor, (uint32_t *)nullptr, counts, base, sem, d_agg, d_meta, K1, caps, raw, 0u,
+                                          lb_dead, ph, stamp);
+        wave_sync(); // the wave's LDS is reused by the next tile
+        r0 = r0n; r1 = r1n; bpos0 = bposn; rs0 = rs0n; r0n = r0nn; r1n = r1nn;
+        t = tn;
+        tn = tnn;
+        if (tnn < n_tiles) tnn = drawn; // >= n_tiles: this wave's cursor has run dry
+    }
+}
+
+template <int L>
+hipError_t launch_stream_l(hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases, uint64_t n_tiles_full,
+                           const uint32_t *tile_read0, Sem sem, Records rec, uint64_t *pool_cursor, Counts *counts, const Desc *desc, uint64_t tile_begin) {
+    if constexpr (L > 0) {
+        auto kern = stream_minimizer_kernel<L>;
+        constexpr int lds = stream_lds_bytes();
+        constexpr int MAX_DEV = 64;
+        static int n_cu_d[MAX_DEV] = {0};
+        static std::mutex cache_mu;
+        int dev = 0;
+        S2K_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= MAX_DEV) return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> lk(cache_mu);
+        if (n_cu_d[dev] == 0) {
+            S2K_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipDeviceProp_t prop;
+            S2K_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+            n_cu_d[dev] = prop.multiProcessorCount;
+        }
+        uint64_t blocks = (n_tiles_full - tile_begin + STREAM_TW - 1) / STREAM_TW;
+        const uint64_t resident = (uint64_t)n_cu_d[dev] * STREAM_BPC;
+        if (blocks > resident) blocks = resident; // persistent: waves loop over the remaining tiles
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * STREAM_TW), lds, st, bases, read_off, n_reads, n_bases, n_tiles_full, tile_read0, sem, rec,
+                           pool_cursor, counts, desc->agg, desc->meta, desc->k - 1u, tile_begin);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+#endif // S2K_STREAM_BUILD
+
 template <int L, bool HPC, bool DESC>
 hipError_t launch_tiles_lh(hipStream_t st, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, uint64_t n_bases,
                            uint64_t n_tiles, const uint32_t *tile_read0, Sem sem, Records rec, uint64_t *pool_cursor,
@@ -2047,6 +2221,25 @@ hipError_t launch_tiles_l(bool hpc, hipStream_t st, const uint8_t *bases, const 
 #define S2K_GO(H, F)                                                                                                       \
     launch_tiles_lh<L, H, F>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, tile_rec_off, \
                              tile_cnt, mn_cnt, counts, desc, tile_begin)
+#if S2K_STREAM_BUILD
+    if constexpr (L > 0) {
+        // Regular family, descriptor path: the tiles that lie wholly inside the stream (all but the last one or two) go to the kernel without a
+        // tile buffer; S2K_STREAM_KERNEL=0 keeps the tiled kernel for everything (A/B runs)
+        static const bool use_stream = S2K_STREAM_DEFAULT ? !(getenv("S2K_STREAM_KERNEL") && atoi(getenv("S2K_STREAM_KERNEL")) == 0)
+                                                          : (getenv("S2K_STREAM_KERNEL") && atoi(getenv("S2K_STREAM_KERNEL")) != 0);
+        if (desc && !hpc && use_stream) {
+            const uint64_t n_full = n_bases >= 128 ? (n_bases - 128) / (uint64_t)TILE_BASES : 0; // tiles t with (t + 1) TILE_BASES + 128 <= n_bases
+            const uint64_t hi = n_full < n_tiles ? n_full : n_tiles;
+            if (hi > tile_begin) {
+                S2K_HIP_CHECK(launch_stream_l<L>(st, bases, read_off, n_reads, n_bases, hi, tile_read0, sem, rec, pool_cursor, counts, desc, tile_begin));
+                if (hi >= n_tiles) return hipSuccess;
+                const uint64_t tb = hi; // (the one or two tiles at the end of the stream: no draws from the cursors, which the launch above has used)
+                return launch_tiles_lh<L, false, true>(st, bases, read_off, n_reads, n_bases, n_tiles, tile_read0, sem, rec, pool_cursor, tile_rec_off, tile_cnt,
+                                                       mn_cnt, counts, desc, tb);
+            }
+        }
+    }
+#endif
     if (desc) return hpc ? S2K_GO(true, true) : S2K_GO(false, true);
     return hpc ? S2K_GO(true, false) : S2K_GO(false, false);
 #undef S2K_GO

@@ -47,8 +47,10 @@ def test_profile_and_knobs_configurations_still_compile():
     fires in those configurations (round 5: the PROFILE accumulators pushed the Regular block over 160 KiB of LDS) would go unnoticed
     until a GPU call is spent on it.  Syntax-only, host + device passes, a few seconds each."""
     csrc = os.path.join(ROOT, "rust-seq2kminmers_amd", "csrc")
-    for flags in (["-DS2K_PROFILE", "-DS2K_DEBUG_KNOBS"], ["-DS2K_DEBUG_KNOBS"]):
-        r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", *flags, "s2k_tile.hip"],
+    # (-DS2K_STREAM_BUILD=1: the Regular kernel without a tile buffer, measured slower and left out of the default build -- profiles/r06_stream.txt)
+    for flags, src in ((["-DS2K_PROFILE", "-DS2K_DEBUG_KNOBS"], "s2k_tile.hip"), (["-DS2K_DEBUG_KNOBS"], "s2k_tile.hip"),
+                       (["-DS2K_STREAM_BUILD=1", "-DS2K_TILE_L=31"], "s2k_tile_inst.hip")):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", *flags, src],
                            cwd=csrc, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (flags, r.stderr[-3000:])
 
