@@ -118,6 +118,28 @@ def physical_cores():
         return None
 
 
+def bind_to_gpu_node(props):
+    """Runs this rank on the CPUs of the NUMA node its GPU hangs off (what `numactl --cpunodebind` does for a deployed rank): on a two-socket host a
+    1-GPU job's CPU share is a quota, not a placement, and the PCIe-inclusive legs moved between 50 and 140 Gbp/s with the socket the process happened
+    to start on (profiles/r06_e2e_numa_bind.txt).  Returns the node, or None when sysfs does not name one (nothing is changed then)."""
+    try:
+        bus = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
 def usable_cpus():
     """CPUs this process may actually use: the affinity mask and the cgroup CPU quota both bound it (a GPU box hands a
     1-GPU job a share of the host, e.g. 16 of 256 hardware threads: timing 256 threads there measures the quota)."""
@@ -264,6 +286,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the few collective words live
     torch.cuda.set_device(dev)
+    numa_node = None if os.environ.get("S2K_BENCH_NO_NUMA") else bind_to_gpu_node(torch.cuda.get_device_properties(dev))
     collective = None
     if dist is not None:
         # proof that the process group really spans N ranks on N devices: every rank contributes (rank, device index, PCI bus id)
@@ -764,7 +787,7 @@ def main():
         except OSError as ex:  # no room for the file: the leg is skipped, the bench line stands
             file_leg = "n/a (%s)" % type(ex).__name__
         e2e = {"gbp": round(ne * rl / 1e9, 2), "extract_gbp_s": legs[args.mode]["gbp_s"], "extract_other_mode_gbp_s": legs["regular" if args.mode == "hpc" else "hpc"]["gbp_s"],
-               "h2d_bytes": legs[args.mode]["h2d"], "d2h_bytes": legs[args.mode]["d2h"], "run_file_gbp_s": file_leg, "host_cpus": usable_cpus()}
+               "h2d_bytes": legs[args.mode]["h2d"], "d2h_bytes": legs[args.mode]["d2h"], "run_file_gbp_s": file_leg, "host_cpus": usable_cpus(), "numa_node": numa_node}
         del hb
 
     # ---- CPU baseline: the oracle = scalar port of the reference, on this host's cores --------------

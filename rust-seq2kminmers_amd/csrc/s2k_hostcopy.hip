@@ -5,13 +5,70 @@
 #include <cstdlib>
 #include <cstring>
 #include <immintrin.h>
+#include <cctype>
+#include <cstdio>
+#include <pthread.h>
 #include <sched.h>
 
 namespace s2k {
 
+// The CPUs of the NUMA node the current HIP device hangs off (sysfs: the device's PCI address -> numa_node -> the node's cpulist).  A 1-GPU job on a
+// two-socket host may run anywhere (its CPU share is a quota, not an affinity mask): copy threads on the far socket read the caller's pages and write the
+// pinned ring across the socket link, and s2k_extract moved between 50 and 139 Gbp/s from one process to the next (profiles/r06_e2e_*.txt).  Bound to the
+// GPU's node the threads at least agree with the pinned ring and the DMA engine.  false: unknown (no sysfs, one node) -- nothing is bound.
+static bool gpu_node_cpus(cpu_set_t *set) {
+    int dev = 0;
+    char bus[64] = {0};
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) return false;
+    for (char *c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0) return false;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return false;
+    char list[4096] = {0};
+    const bool ok = fgets(list, (int)sizeof list, f) != nullptr;
+    fclose(f);
+    if (!ok) return false;
+    CPU_ZERO(set);
+    int n = 0;
+    for (char *p = list; *p;) { // "0-63,128-191"
+        char *e;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET((int)c, set), n++;
+        p = *e == ',' ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    cpu_set_t may; // only CPUs the process may use anyway
+    if (sched_getaffinity(0, sizeof may, &may) == 0) {
+        int both = 0;
+        for (int c = 0; c < CPU_SETSIZE; c++) {
+            if (CPU_ISSET(c, set) && !CPU_ISSET(c, &may)) CPU_CLR(c, set);
+            if (CPU_ISSET(c, set)) both++;
+        }
+        n = both;
+    }
+    return n > 0;
+}
+
 CopyPool::CopyPool(int threads) {
     if (threads < 1) threads = 1;
-    for (int i = 1; i < threads; i++) workers_.emplace_back(&CopyPool::worker, this, i);
+    static const bool bind = !(getenv("S2K_NUMA_BIND") && atoi(getenv("S2K_NUMA_BIND")) == 0);
+    cpu_set_t node;
+    const bool have_node = bind && gpu_node_cpus(&node);
+    for (int i = 1; i < threads; i++) {
+        workers_.emplace_back(&CopyPool::worker, this, i);
+        if (have_node) (void)pthread_setaffinity_np(workers_.back().native_handle(), sizeof node, &node);
+    }
 }
 
 CopyPool::~CopyPool() {
