@@ -195,11 +195,11 @@ __device__ inline uint32_t dk_lane(uint32_t v, int src) { return (uint32_t)__bui
 // (profiles/r06_ab_km1.txt).
 constexpr int DK_STAGE_RECS = 192, DK_STAGE_BYTES = DK_STAGE_RECS * 20; // per wave: {hash, start, end} 16 B + {window index | rev << 31} 4 B per minimizer of a batch
 template <int KT, bool FULL, bool COAL = false>
-__global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kernel(uint64_t tile_begin, uint64_t tile_end, uint64_t n_tiles, uint64_t n_reads, Desc dz,
+__global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t tile_begin, uint64_t tile_end, uint64_t n_tiles, uint64_t n_reads, Desc dz,
                                                                         Records rec, Counts *counts) {
     // compile-time k (lane-serial windows, below): the ring only carries the k-1 minimizers before a batch (+ the 64 counts of the slow look-back, which
     // share its upper entries); run-time k: a round's 64 mixed hashes behind them
-    __shared__ unsigned long long s_ring[DK_WAVES][(KT > 0 ? 32 : 64) + DK_KMAX];
+    __shared__ unsigned long long s_ring[DK_WAVES][((KT > 0 && FULL) ? 32 : 64) + DK_KMAX];
     __shared__ uint4 s_seg[DK_WAVES][META_SEGS]; // per read segment of the tile: {hits before it, hit index -> window index, (tile start - read start) mod 2^32, -}
     __shared__ uint32_t s_jcar[DK_WAVES][DK_KMAX];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // w in an SGPR: per-tile values are scalar
@@ -221,11 +221,15 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
     const uint64_t slab = t * rec.slab_cap;
     uint32_t nh32 = rec.hash[slab + lane], npos = rec.j[slab + lane]; // (slab_cap >= 64: always inside the pool)  [run-time k only]
     constexpr bool KFIX = KT > 0;
+    // SERIAL: lane-serial windows (below) for the common call -- compile-time k, all four k-min-mer arrays, no minimizer triples.  The other calls keep the
+    // one-minimizer-per-lane rounds of rounds 3-5: their extra arrays (triples) would be written with a stride too, and alone that costs more than the
+    // rolling windows save (minimizers beside the k-min-mers, Regular: 1760 -> 1539 Gbp/s with the lane-serial kernel, bench line of round 6's first runs)
+    constexpr bool SERIAL = KFIX && FULL;
     // compile-time k: the lane's three consecutive records, fetched under the assumptions that hold for all but a few tiles of a call -- 129 .. 192 minimizers
     // (three per lane, below), in the tile's own slab -- so that the records travel with the first round trip instead of behind the tile's word
     // (the addresses stay inside the pool whatever the slab holds: the overflow region and the arena's slack lie behind the last slab)
     uint32_t sp_h0 = 0, sp_h1 = 0, sp_h2 = 0, sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // (scalars: as arrays the lambda below would keep them in scratch)
-    if constexpr (KFIX) {
+    if constexpr (SERIAL) {
         const uint32_t *ph = rec.hash + slab + 3u * (uint32_t)lane, *pp = rec.j + slab + 3u * (uint32_t)lane;
         sp_h0 = ph[0], sp_h1 = ph[1], sp_h2 = ph[2];
         sp_p0 = pp[0], sp_p1 = pp[1], sp_p2 = pp[2];
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, FULL ? 8 : 6) void desc_kminmer_kern
     unsigned long long *const t_hash = dz.o_hash + G;
     uint32_t *const t_start = dz.o_start + G, *const t_end = dz.o_end + G;
     uint8_t *const t_rev = dz.o_rev + G;
-    if constexpr (KFIX) {
+    if constexpr (SERIAL) {
     // ---- compile-time k: LANE-SERIAL windows (round 6).  A lane takes RB CONSECUTIVE minimizers (RB = 1 .. 4 by the tile's count: 64 RB of them per
     //      batch, one batch as a rule), so that only its first window pays the closed form (src/lib.rs:275-288: 2 k rotations of 64 bits) and the next
     //      ones ROLL (src/lib.rs:243-249: F' = rotl(F, 1) ^ rotl(out, k) ^ in, Rv' = rotr(Rv ^ out, 1) ^ rotl(in, k-1): 14 instructions instead of 58).
