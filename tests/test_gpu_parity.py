@@ -173,6 +173,45 @@ def test_one_high_byte_does_not_change_the_path(eng, oracle):
         assert a["n"] == b["n"] and (a["hash"] == b["hash"]).all()
 
 
+def test_every_packing_routine_rebuilds_the_same_stream(oracle, tmp_path):
+    """The 2-bit packing of host bases has three implementations (scalar, AVX2 + pext, AVX-512; S2K_PACK_ISA picks one, the default is the best the
+    CPU has -- read once per process, hence the children): each must hand the device the caller's bytes exactly, exceptions (N runs, lower case,
+    bytes >= 0x80, a zero byte) included, also when a group of 64 / 32 bases straddles them and when the stream does not end on a group."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    rng = np.random.default_rng(177)
+    n = 9_000_003  # (> 8 MiB: packed; not a multiple of 64)
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+    for a in rng.integers(0, n - 100, size=400):
+        s[a:a + int(rng.integers(1, 70))] = ord("N")
+    odd = rng.integers(0, n, size=3000)
+    s[odd] = np.frombuffer(b"nacgtXR*-\xc1\x00", dtype=np.uint8)[rng.integers(0, 11, size=len(odd))]
+    lens = []
+    while sum(lens) < n:
+        lens.append(int(rng.integers(500, 40000)))
+    off = np.minimum(np.concatenate([[0], np.cumsum(lens)]), n).astype(np.uint64)
+    ref = oracle.batch(s, off, 31, 10, 0.01, 1, threads=4)
+    np.save(tmp_path / "s.npy", s)
+    np.save(tmp_path / "off.npy", off)
+    child = ("import sys, os, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+             "from gpu_util import pkg\n"
+             "s = np.load(%r); off = np.load(%r)\n"
+             "eng = pkg.Engine(0); got = eng.extract(s, off, 31, 10, 0.01, pkg.HashMode.Hpc)\n"
+             "np.savez(sys.argv[1], **{f: got[f] for f in ('hash', 'start', 'end', 'rev', 'km_off')})\n") % (
+                 ROOT, ROOT, str(tmp_path / "s.npy"), str(tmp_path / "off.npy"))
+    for isa in ("0", "1", "2"):
+        out = str(tmp_path / ("isa%s.npz" % isa))
+        r = subprocess.run([sys.executable, "-c", child, out], env=dict(os.environ, S2K_PACK_ISA=isa), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (isa, r.stderr[-2000:])
+        got = np.load(out)
+        assert len(got["hash"]) == ref["n"], isa
+        for f in FIELDS:
+            assert (got[f] == ref[f]).all(), (isa, f)
+
+
 def test_packed_host_transfer_is_exact(eng, oracle):
     """s2k_extract sends the bases 2-bit packed over PCIe (copy threads pack while they fill the pinned ring; every byte that
     is not A/C/G/T travels in an exception list; a chunk that is mostly not DNA text goes as it is).  The stream rebuilt on
