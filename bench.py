@@ -554,7 +554,9 @@ def main():
     other_line = None
     if not args.no_other_mode:
         s2 = max(2, args.steps // 2)
-        dt2, counts2, min_ms2, km_ms2, pipe_ms2, _ = timed(other, s2, 1)
+        # (the same number of warm-up steps as the headline: this leg starts behind seconds of host-side verification, i.e. on an idle chip whose clocks
+        # take a few steps to come up -- with one warm-up step the Regular kernel read 4.2-4.4 ms here against 3.9 ms in a process of its own)
+        dt2, counts2, min_ms2, km_ms2, pipe_ms2, _ = timed(other, s2, max(1, args.warmup))
         alg2 = counts2["n_bases"] + 17 * counts2["n_kminmers"] + 16 * (n_reads + 1)
         tot2 = sharding.allreduce_counts(counts2, dist, red_dev)
         other_line = {"mode": "regular" if args.mode == "hpc" else "hpc", "value": round(tot2["n_bases"] * s2 / dt2 / 1e9, 2), "unit": "Gbp/s",
@@ -566,7 +568,7 @@ def main():
         compat = {}
         for nm, hm in (("simd", pkg.HashMode.Simd), ("hpcsimd", pkg.HashMode.HpcSimd)):
             s3 = max(2, args.steps // 4)
-            dt3, counts3, _, _, pipe_ms3, _ = timed(hm, s3, 1, strict=False)
+            dt3, counts3, _, _, pipe_ms3, _ = timed(hm, s3, max(1, args.warmup // 2), strict=False)
             assert counts3["path"] == (2 if args.legacy_path else 0)
             tot3 = sharding.allreduce_counts(counts3, dist, red_dev)
             compat[nm] = {"value": round(tot3["n_bases"] * s3 / dt3 / 1e9, 1), "pipeline_ms": round(pipe_ms3, 3), "reruns": int(timed.reruns)}

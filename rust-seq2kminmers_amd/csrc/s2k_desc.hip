@@ -478,11 +478,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
                 *reinterpret_cast<lds_u1 *>(stage + 16u * DK_STAGE_RECS + 4u * e) = win ? ((i + adj[r]) | (rvv < f ? 0x80000000u : 0u)) : 0xFFFFFFFFu;
             } else
             if (win) {
-#ifdef S2K_KM_FAKE_COAL // (timing experiment only, WRONG results: what would the kernel take if its stores were contiguous across the lanes?)
-                const uint32_t ot = b0 + 64u * (uint32_t)r + (uint32_t)lane_b + (adj[r] & 0u);
-#else
                 const uint32_t ot = i + adj[r]; // index among the tile's windows (>= 0 for a window)
-#endif
                 xacc ^= hmin;
                 if (tile_fits) { // (wave-uniform) FULL and everything fits: scalar base + 32-bit offset, no tests
                     t_hash[ot] = hmin;

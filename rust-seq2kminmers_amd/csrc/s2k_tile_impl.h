@@ -1742,9 +1742,8 @@ __global__ __launch_bounds__(64 * tw<HPC>(), waves_per_simd<HPC>()) void tile_mi
         r1n = tile_read0[tn + 1];
     }
 
-#ifdef S2K_TILE_PRIO // (experiment: the persistent kernel's waves above the k-min-mer kernel's beside them in the SIMD's issue arbitration)
-    if (!sem.tile_heads) __builtin_amdgcn_s_setprio(S2K_TILE_PRIO);
-#endif
+    // (the persistent kernel's waves at a raised issue priority over the k-min-mer kernel's beside them -- s_setprio 1 / 3 for the whole kernel -- changed nothing:
+    // profiles/r06_chunks_prio_sweep.txt)
     uint32_t prio_iter = 0;
     // HpcSimd look-back (lookback_heads): a wave that has waited in vain once does not wait again -- nor does any wave once the
     // call is known to be run again (need_runs; e.g. the minimizer kernel of a later chunk)

@@ -49,7 +49,8 @@ def test_profile_and_knobs_configurations_still_compile():
     csrc = os.path.join(ROOT, "rust-seq2kminmers_amd", "csrc")
     # (-DS2K_STREAM_BUILD=1: the Regular kernel without a tile buffer, measured slower and left out of the default build -- profiles/r06_stream.txt)
     for flags, src in ((["-DS2K_PROFILE", "-DS2K_DEBUG_KNOBS"], "s2k_tile.hip"), (["-DS2K_DEBUG_KNOBS"], "s2k_tile.hip"),
-                       (["-DS2K_STREAM_BUILD=1", "-DS2K_TILE_L=31"], "s2k_tile_inst.hip")):
+                       (["-DS2K_STREAM_BUILD=1", "-DS2K_TILE_L=31"], "s2k_tile_inst.hip"),
+                       (["-DS2K_LPH=1", "-DS2K_TILE_L=31"], "s2k_tile_inst.hip")):  # (one lane per hit in the listing: measured slower, off by default)
         r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", *flags, src],
                            cwd=csrc, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (flags, r.stderr[-3000:])

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (prio1.so / prio3.so of this sweep were builds with -DS2K_TILE_PRIO=1 / 3 -- one s_setprio at the head of the tile kernel -- of commit "k-min-mer kernel: records fetched with the first round trip ..."; the experiment code has since been removed)
 # round 6: Hpc step against the chunk count (S2K_DESC_CHUNKS), with and without staged stores for the last chunk's k-min-mer kernel (S2K_KM_TAIL_COAL), and the
 # tile kernel's waves at a raised issue priority: tools/ab/r6_sweep.sh
 cd $GRAFT_REPO_ROOT
