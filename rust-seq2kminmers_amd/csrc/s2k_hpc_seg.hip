@@ -62,7 +62,8 @@ __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
     uint32_t *__restrict__ o_pos, uint64_t capacity, bool rle) {
     __shared__ uint32_t starts[HS_SEG / 32]; // bit i: a non-empty read starts at seg + i
     __shared__ uint32_t ws[HS_THREADS / 64], wm[HS_THREADS / 64];
-    __shared__ uint32_t out_p[HS_SEG];
+    __shared__ uint32_t out_p[HS_SEG]; // (staged as 16-bit offsets and resolved at the write -- 14 KiB, eight blocks per CU instead of seven -- the kernel was 8 % SLOWER:
+                                       // the write loop of a segment that holds read starts pays a dozen instructions per run head; profiles/r06_hpc_two_pass_trims.txt)
     __shared__ __attribute__((aligned(16))) uint8_t out_b[HS_SEG + 16];
     const int t = threadIdx.x;
     const uint64_t seg = (uint64_t)blockIdx.x * HS_SEG, seg_end = seg + HS_SEG;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(HS_THREADS) void hpc_segment_kernel(
     int nval = 0;
     if (q0 < n_bases) {
         nval = n_bases - q0 >= 16 ? 16 : (int)(n_bases - q0);
-        if (q0) prev = s[q0 - 1];
+        if (q0) prev = s[q0 - 1]; // (taken from the lane before instead -- one byte load per wave -- the kernel was 2 % SLOWER: profiles/r06_hpc_two_pass_trims.txt)
         if (nval == 16) v = *reinterpret_cast<const uint4 *>(s + q0);
     }
     // starts of the non-empty reads inside the segment (read r_s itself when it starts exactly here); none in most segments of long reads

@@ -257,38 +257,57 @@ hipError_t launch_finalize(Counts *counts, const uint64_t *xor_shards, const uin
 namespace {
 constexpr int RUN_BLK = 256;
 
+// Four 4 KiB stretches per block (16 bytes per thread each, all four loads in flight); the byte before a thread's 16 comes from the lane before it
+// (its last byte), only lane 0 of a wave fetches it from memory (round 6: one vector load per thread and stretch instead of two, 4 in flight instead of 1)
+constexpr int RUN_UNROLL = 4;
 __global__ __launch_bounds__(256) void run_block_counts(const uint8_t *__restrict__ s, uint64_t n, uint32_t *__restrict__ cnt, bool rle) {
-    const uint64_t q0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; // 16 bytes per thread, 16 threads per block of 256
-    uint32_t c = 0;
-    if (q0 < n) {
-        uint32_t prev = q0 ? s[q0 - 1] : 0x100u;
-        if (q0 + 16 <= n && !rle) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(s + q0);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const int lane = threadIdx.x & 63;
+    uint64_t q0[RUN_UNROLL];
+    uint4 v[RUN_UNROLL];
+    uint32_t pm[RUN_UNROLL];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t prv = (w[i] << 8) | (prev & 0xFFu);
-                uint32_t x = w[i] ^ prv; // byte j != 0 <=> s[q] != s[q-1]
-                uint32_t nz = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu | x) & 0x80808080u;
-                if (i == 0 && prev == 0x100u) nz |= 0x80u; // q == 0
-                c += __popc(nz);
-                prev = w[i] >> 24;
-            }
-        } else {
-            for (uint64_t q = q0; q < n && q < q0 + 16; q++) { // tail of the stream, and the encode_rle flavour
-                const uint32_t b = s[q];
-                c += (prev == 0x100u || run_head(b, prev, rle)) ? 1u : 0u;
-                prev = b;
+    for (int k = 0; k < RUN_UNROLL; k++) {
+        q0[k] = (((uint64_t)blockIdx.x * RUN_UNROLL + k) * 256 + threadIdx.x) * 16; // 16 bytes per thread, 16 threads per block of 256
+        v[k] = make_uint4(0, 0, 0, 0);
+        pm[k] = 0x100u;
+        if (q0[k] + 16 <= n && !rle) v[k] = *reinterpret_cast<const uint4 *>(s + q0[k]);
+        if (q0[k] < n && q0[k] && (lane == 0 || rle)) pm[k] = s[q0[k] - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < RUN_UNROLL; k++) {
+        uint32_t c = 0;
+        if (q0[k] < n) {
+            // the lane before holds the 16 bytes that end where this lane's begin (it lies inside the stream: fully loaded)
+            const uint32_t from_lane = (uint32_t)__shfl_up((int)(v[k].w >> 24), 1);
+            uint32_t prev = (lane == 0 || rle) ? pm[k] : from_lane;
+            if (q0[k] + 16 <= n && !rle) {
+                const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t prv = (w[i] << 8) | (prev & 0xFFu);
+                    uint32_t x = w[i] ^ prv; // byte j != 0 <=> s[q] != s[q-1]
+                    uint32_t nz = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu | x) & 0x80808080u;
+                    if (i == 0 && prev == 0x100u) nz |= 0x80u; // q == 0
+                    c += __popc(nz);
+                    prev = w[i] >> 24;
+                }
+            } else {
+                if (!rle && q0[k]) prev = s[q0[k] - 1]; // (the stream's last, partial 16 bytes: the lane before may not have loaded)
+                for (uint64_t q = q0[k]; q < n && q < q0[k] + 16; q++) { // tail of the stream, and the encode_rle flavour
+                    const uint32_t b = s[q];
+                    c += (prev == 0x100u || run_head(b, prev, rle)) ? 1u : 0u;
+                    prev = b;
+                }
             }
         }
+        // 16 consecutive threads share a block
+        c += __shfl_xor(c, 1);
+        c += __shfl_xor(c, 2);
+        c += __shfl_xor(c, 4);
+        c += __shfl_xor(c, 8);
+        const uint64_t blk = q0[k] / RUN_BLK;
+        if ((threadIdx.x & 15) == 0 && blk * RUN_BLK < n + RUN_BLK) cnt[blk] = c;
     }
-    // 16 consecutive threads share a block
-    c += __shfl_xor(c, 1);
-    c += __shfl_xor(c, 2);
-    c += __shfl_xor(c, 4);
-    c += __shfl_xor(c, 8);
-    const uint64_t blk = q0 / RUN_BLK;
-    if ((threadIdx.x & 15) == 0 && blk * RUN_BLK < n + RUN_BLK) cnt[blk] = c;
 }
 
 // Run heads in [start of b's 256-byte block, b) that fall into the 16 bytes lane `sub` of a 16-lane group looks at; the group's sum
@@ -452,7 +471,7 @@ hipError_t launch_read_run_counts(const uint8_t *bases, const uint64_t *read_off
     if (n_reads == 0) return hipSuccess;
     const uint64_t nblk = n_bases / RUN_BLK + 1; // the block that holds position n_bases exists too (count 0 past the end)
     const uint64_t threads = nblk * 16;
-    hipLaunchKernelGGL(run_block_counts, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, bases, n_bases, blk_cnt, rle);
+    hipLaunchKernelGGL(run_block_counts, dim3((unsigned)((threads + 256 * RUN_UNROLL - 1) / (256 * RUN_UNROLL))), dim3(256), 0, st, bases, n_bases, blk_cnt, rle);
     hipError_t e = launch_scan_u32(blk_cnt, nblk, blk_off, scan_tmp, 0, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(read_run_counts, dim3((unsigned)((n_reads * 16 + 255) / 256)), dim3(256), 0, st, bases, n_bases, read_off, n_reads,
