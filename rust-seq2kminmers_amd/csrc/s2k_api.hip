@@ -228,6 +228,7 @@ struct s2k_ctx {
     hipStream_t s_in = nullptr, s_out = nullptr;  // s2k_extract: H2D of the next / D2H of the previous sub-batch
     hipStream_t s_km = nullptr;                   // descriptor path: scan + k-min-mer kernel of chunk c run here, beside the minimizer kernel of chunk c+1
     std::vector<hipEvent_t> chunk_ev;             // fork / per-chunk / join events of that pipeline (no timing)
+    uint32_t rec_per_tile_hint = 0;               // minimizers per tile of the last descriptor-path call (+ margin): Desc::spec_n
     s2k_ctx *chain_prev = nullptr;                // s2k_chain_after: this context's minimizer kernels wait for tiles_done of that one
     hipEvent_t tiles_done = nullptr;              // recorded behind the last minimizer kernel of a call (created on first use)
     bool tiles_done_valid = false;
@@ -540,6 +541,9 @@ s2k_status enqueue(s2k_ctx *ctx) {
             dz.meta = d_meta;
             dz.state = d_state;
             dz.k = c.sem.k;
+            // the k-min-mer kernel fetches a tile's records before it knows how many there are: as many as the tiles of this context's last call of the same
+            // shape held on average, + 4 sigma of a Poisson count (first call: a full 192) -- a tile with more fetches again, one with fewer wasted little
+            dz.spec_n = ctx->rec_per_tile_hint ? ctx->rec_per_tile_hint : 192u;
             dz.km_capacity = o.km_capacity;
             dz.mn_capacity = o.mn_capacity;
             dz.o_km_off = (unsigned long long *)o.km_off;
@@ -692,6 +696,11 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
             s2k_status st = enqueue(ctx);
             if (st != S2K_OK) return st;
             continue;
+        }
+        if (c.desc_run && c.n_bases >= 64u * (uint64_t)TILE_BASES) { // (see enqueue: Desc::spec_n of the next call)
+            const double avg = (double)h->n_minimizers / ((double)c.n_bases / (double)TILE_BASES);
+            const double want = avg + 4.0 * sqrt(avg + 1.0) + 3.0;
+            ctx->rec_per_tile_hint = want >= 192.0 ? 192u : (uint32_t)want;
         }
         h->n_reads = c.n_reads;
         h->n_bases = c.n_bases;

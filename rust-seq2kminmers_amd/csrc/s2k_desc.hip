@@ -230,9 +230,11 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
     // (the addresses stay inside the pool whatever the slab holds: the overflow region and the arena's slack lie behind the last slab)
     uint32_t sp_h0 = 0, sp_h1 = 0, sp_h2 = 0, sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // (scalars: as arrays the lambda below would keep them in scratch)
     if constexpr (SERIAL) {
-        const uint32_t *ph = rec.hash + slab + 3u * (uint32_t)lane, *pp = rec.j + slab + 3u * (uint32_t)lane;
-        sp_h0 = ph[0], sp_h1 = ph[1], sp_h2 = ph[2];
-        sp_p0 = pp[0], sp_p1 = pp[1], sp_p2 = pp[2];
+        if (3u * (uint32_t)lane < dz.spec_n) { // (the lanes that the expected number of records reaches: Desc::spec_n)
+            const uint32_t *ph = rec.hash + slab + 3u * (uint32_t)lane, *pp = rec.j + slab + 3u * (uint32_t)lane;
+            sp_h0 = ph[0], sp_h1 = ph[1], sp_h2 = ph[2];
+            sp_p0 = pp[0], sp_p1 = pp[1], sp_p2 = pp[2];
+        }
     }
     if (off_flags) return;
     const uint32_t k = KFIX ? (uint32_t)KT : dz.k, K1 = k - 1;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
         // the lane's records: RB consecutive entries of each array (reads past the tile's last record stay inside the pool: the arena keeps slack)
         bool pre = false;
         if constexpr (RB == 3) {
-            if (b0 == 0u && base == slab) { // (wave-uniform) what the first round trip fetched is what this batch wants
+            if (b0 == 0u && base == slab && N <= dz.spec_n) { // (wave-uniform) what the first round trip fetched is what this batch wants
                 pre = true;
                 h32[0] = sp_h0, h32[1] = sp_h1, h32[2] = sp_h2;
                 pos[0] = sp_p0, pos[1] = sp_p1, pos[2] = sp_p2;

@@ -206,7 +206,8 @@ struct Desc { // arguments of the descriptor path (device pointers)
     unsigned long long *agg; // n_tiles
     TileMeta *meta;          // n_tiles
     TileState *state;        // n_tiles + 1 (the last entry holds the totals)
-    uint32_t k, pad_;
+    uint32_t k;
+    uint32_t spec_n; // records of a tile the k-min-mer kernel fetches with its first round trip (three per lane): the context's guess from its last call (0: none)
     unsigned long long km_capacity, mn_capacity;
     unsigned long long *o_km_off, *o_hash;
     uint32_t *o_start, *o_end;
