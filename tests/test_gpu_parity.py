@@ -173,6 +173,21 @@ def test_one_high_byte_does_not_change_the_path(eng, oracle):
         assert a["n"] == b["n"] and (a["hash"] == b["hash"]).all()
 
 
+def test_kminmer_kernel_when_its_guess_of_the_record_count_is_wrong(oracle):
+    """The k-min-mer kernel fetches a tile's records with its first round trip, as many as the tiles of the context's LAST call held on average
+    (+ 4 sigma; Desc::spec_n): a call of another shape on the same context meets tiles with more records than were fetched (they fetch again) and
+    tiles with far fewer.  Sparse -> dense -> sparse on one context, k-min-mers only (the lane-serial kernel), every tuple against the oracle."""
+    rng = np.random.default_rng(606)
+    reads = [rand_read(rng, int(n)) for n in rng.integers(4000, 40000, size=60)]  # ~1.3 Mbp: > 64 tiles, the hint is updated
+    own = pkg.Engine(0)
+    try:
+        for mode in (HM.Regular, HM.Hpc):
+            for d in (0.002, 0.019, 0.01, 0.03, 0.001):  # ~37, ~350, ~184, ~550, ~18 minimizers per Regular tile
+                compare(own, oracle, reads, 31, 10, d, mode, expect_path="desc", minimizers=False, tag="spec_n")
+    finally:
+        own.close()
+
+
 def test_every_packing_routine_rebuilds_the_same_stream(oracle, tmp_path):
     """The 2-bit packing of host bases has three implementations (scalar, AVX2 + pext, AVX-512; S2K_PACK_ISA picks one, the default is the best the
     CPU has -- read once per process, hence the children): each must hand the device the caller's bytes exactly, exceptions (N runs, lower case,
