@@ -542,7 +542,7 @@ s2k_status enqueue(s2k_ctx *ctx) {
             dz.state = d_state;
             dz.k = c.sem.k;
             // the k-min-mer kernel fetches a tile's records before it knows how many there are: as many as the tiles of this context's last call of the same
-            // shape held on average, + 4 sigma of a Poisson count (first call: a full 192) -- a tile with more fetches again, one with fewer wasted little
+            // shape held on average, + 2.5 sigma of a Poisson count (first call: a full 192) -- a tile with more fetches again, one with fewer wasted little
             dz.spec_n = ctx->rec_per_tile_hint ? ctx->rec_per_tile_hint : 192u;
             dz.km_capacity = o.km_capacity;
             dz.mn_capacity = o.mn_capacity;
@@ -699,7 +699,7 @@ s2k_status finish(s2k_ctx *ctx, s2k_counts *counts) {
         }
         if (c.desc_run && c.n_bases >= 64u * (uint64_t)TILE_BASES) { // (see enqueue: Desc::spec_n of the next call)
             const double avg = (double)h->n_minimizers / ((double)c.n_bases / (double)TILE_BASES);
-            const double want = avg + 4.0 * sqrt(avg + 1.0) + 3.0;
+            const double want = avg + 2.5 * sqrt(avg + 1.0) + 3.0; // (a tile in ~100 holds more and fetches again; every lane not fetched saves 24 B per tile)
             ctx->rec_per_tile_hint = want >= 192.0 ? 192u : (uint32_t)want;
         }
         h->n_reads = c.n_reads;
@@ -1427,7 +1427,6 @@ s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_
     // memory, so the prefixes spread over the 488 k blocks of 2 Gbp at that latency whatever the window (64 words per look: 4.58 ms; 256: 5.64 ms;
     // two passes: 2.66 ms -- profiles/r06_hpc_single_pass_*.txt).  Kept selectable, not used.
     static const bool single_pass_env = getenv("S2K_HPC_SINGLE_PASS") != nullptr;
-    bool single_done = false;
     if (seg_path && single_pass_env) {
         uint32_t *fail_word = nullptr;
         S2K_TRY(launch_hpc_single_pass(d_bases, d_read_off, n_reads, n_bases, lb_ws, d_hpc_off, d_hpc, d_pos, capacity, &fail_word, ctx->stream, rle),
@@ -1441,7 +1440,6 @@ s2k_status s2k_hpc_device_ex(s2k_ctx *ctx, const uint8_t *d_bases, const uint64_
             if (n_runs) *n_runs = total1;
             return total1 > capacity && (d_hpc || d_pos) ? S2K_ERR_CAPACITY : S2K_OK;
         }
-        (void)single_done;
     }
     if (seg_path) {
         S2K_TRY(launch_read_run_counts(d_bases, d_read_off, n_reads, n_bases, blk_cnt, blk_off, blk_tmp, cnt, read_c0, ctx->stream, rle),

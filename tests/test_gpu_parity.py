@@ -175,7 +175,7 @@ def test_one_high_byte_does_not_change_the_path(eng, oracle):
 
 def test_kminmer_kernel_when_its_guess_of_the_record_count_is_wrong(oracle):
     """The k-min-mer kernel fetches a tile's records with its first round trip, as many as the tiles of the context's LAST call held on average
-    (+ 4 sigma; Desc::spec_n): a call of another shape on the same context meets tiles with more records than were fetched (they fetch again) and
+    (+ 2.5 sigma; Desc::spec_n): a call of another shape on the same context meets tiles with more records than were fetched (they fetch again) and
     tiles with far fewer.  Sparse -> dense -> sparse on one context, k-min-mers only (the lane-serial kernel), every tuple against the oracle."""
     rng = np.random.default_rng(606)
     reads = [rand_read(rng, int(n)) for n in rng.integers(4000, 40000, size=60)]  # ~1.3 Mbp: > 64 tiles, the hint is updated
