@@ -183,6 +183,25 @@ __device__ inline uint32_t dk_incl_scan(uint32_t v) {
     a += t;
     return a;
 }
+// the same steps with XOR: lane i = XOR of lanes 0 .. i
+__device__ inline uint32_t dk_incl_xor(uint32_t v) {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    uint32_t a = v ^ t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    a ^= t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false); // row_shr:3
+    a ^= t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x114, 0xf, 0xe, false); // row_shr:4, banks 1-3
+    a ^= t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x118, 0xf, 0xc, false); // row_shr:8, banks 2-3
+    a ^= t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+    a ^= t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
+    a ^= t;
+    return a;
+}
 __device__ inline uint32_t dk_lane(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 
 // KT: compile-time k (the window loop is unrolled and reads the ring at constant offsets), or 0: run-time k <= 32
@@ -253,8 +272,17 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
     const uint32_t mine = (uint32_t)lane <= nb ? ((uint32_t)lane < nb ? nextstart : N) - segstart : 0u;
     const uint32_t skip = lane == 0 ? (ag.dep ? K1 - p_in : K1) : K1; // minimizers of a segment that end no k-min-mer
     const uint32_t wseg = (uint32_t)lane <= nb && mine > skip ? mine - skip : 0u;
-    const uint32_t winc = dk_incl_scan(wseg);
-    const uint32_t Wb = winc - wseg, Wt = dk_lane(winc, 63);
+    // windows before each segment / in the whole tile: one or two read starts per tile as a rule -- three readlanes instead of a scan over the wave
+    uint32_t Wb, Wt;
+    if (nb <= 2u) { // (wave-uniform; wseg is 0 beyond lane nb)
+        const uint32_t w0 = dk_lane(wseg, 0), w1 = dk_lane(wseg, 1), w2 = dk_lane(wseg, 2);
+        Wt = w0 + w1 + w2;
+        Wb = lane == 0 ? 0u : (lane == 1 ? w0 : w0 + w1); // (only lanes 0 .. nb read theirs)
+    } else {
+        const uint32_t winc = dk_incl_scan(wseg);
+        Wb = winc - wseg;
+        Wt = dk_lane(winc, 63);
+    }
     if ((uint32_t)lane <= nb) // (read-relative positions are 32-bit: only the low word of tile start - read start is ever needed)
         s_seg[w][lane] = make_uint4(segstart, (uint32_t)((int32_t)Wb - (int32_t)segstart - (int32_t)skip), lane ? 0u - rs16 : (uint32_t)(t0 - rs0), 0u);
     // km_off / mn_off of the reads that start in (t0, end of the tile]: the first nb inside, the rest exactly at the end
@@ -665,8 +693,11 @@ __global__ __launch_bounds__(64 * DK_WAVES, 8) void desc_kminmer_kernel(uint64_t
         jprev = j;
     }
     }
-    for (int o = 32; o > 0; o >>= 1) xacc ^= __shfl_xor(xacc, o);
-    if (lane == 0 && xacc) atomicXor((unsigned long long *)&dz.xor_shards[t & (XOR_SHARDS - 1)], (unsigned long long)xacc);
+    // XOR of the tile's k-min-mer hashes (s2k_counts.xor_hash): folded over the lanes with the DPP steps of dk_incl_scan -- lane 63 ends up with the XOR of all
+    // (round 6; the butterfly of 64-bit shuffles it replaces was twelve ds_bpermute and their waits: a tenth of the kernel's issue slots)
+    const uint32_t xl_all = dk_incl_xor((uint32_t)xacc), xh_all = dk_incl_xor((uint32_t)(xacc >> 32));
+    if (lane == 63 && (xl_all | xh_all))
+        atomicXor((unsigned long long *)&dz.xor_shards[t & (XOR_SHARDS - 1)], ((unsigned long long)xh_all << 32) | xl_all);
 }
 
 } // namespace
