@@ -1403,7 +1403,10 @@ def test_destroying_a_chained_to_context_unlinks_the_survivor(oracle):
 
     run(a)
     run(b)       # both have a recorded tiles_done event now
-    a.close()    # destroyed FIRST, while b is still chained to it
-    run(b)       # must not touch a's event
+    dead = a.ctx  # (the handle's value only: it is compared with the registry of live contexts, never followed)
+    a.close()     # destroyed FIRST, while b is still chained to it
+    run(b)        # must not touch a's event
+    # chaining to a context that is no longer alive is refused (round 6), and leaves b as it was
+    assert b.lib.s2k_chain_after(b.ctx, dead) != 0  # S2K_ERR_INVALID_ARG
     run(b)
     b.close()
